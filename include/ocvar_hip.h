@@ -1,0 +1,112 @@
+/*
+ * ocvar_hip.h -- thin C ABI of the MI355X (gfx950) AR-marker detection path.
+ *
+ * This is the drop-in boundary for the reference's one hot path, cvarArMultRegistration
+ * (/root/reference/include/opencvar/opencvar.h:259-260, /root/reference/src/opencvar.cpp:619-807) and the
+ * functions under it.  Plain pointers and sizes only; no C++ or torch types.  The host-side C++ mirror of
+ * the reference API (include/opencvar/opencvar.h in this repo) is a thin caller of these entry points.
+ *
+ * Which reference interface each entry point stands in for:
+ *   ocvar_hip_set_templates  <- the vector<CvarTemplate> argument (opencvar.h:65-70, filled by
+ *                               cvarLoadTemplateTag/cvarLoadTag, opencvar.cpp:284-321)
+ *   ocvar_hip_set_camera     <- the CvarCamera* argument (opencvar.h:54-60; cvarReadCamera/cvarCameraScale,
+ *                               opencvar.cpp:39-104)
+ *   ocvar_hip_detect_*       <- cvarArMultRegistration for a batch of independent frames (stateless when
+ *                               prev == NULL; with prev it replays the tracking stage, opencvar.cpp:635-668)
+ *   ocvar_hip_find_squares   <- cvarFindSquares + cvarGetAllSquares (opencvar.h:131,240; opencvar.cpp:156-223,564-590)
+ *   ocvar_hip_debug_*        <- no reference counterpart: parity hooks (binary image, pre-dedupe candidates)
+ *
+ * All functions return 0 on success and a negative OCVAR_E_* code on failure; none throws.  There is no
+ * CPU fallback: without a gfx950 device ocvar_hip_create fails.
+ */
+#ifndef OCVAR_HIP_H
+#define OCVAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Layout-identical to the reference's PODs (opencvar.h:54-82); sizes 248 / 48 / 184 bytes. */
+typedef struct { int width, height; double cameraMatrix[9]; double distCoeffs[5]; double glProjection[16]; } OcvarCamera;
+typedef struct { int width, height; double scale; long long code[4]; } OcvarTemplate;
+typedef struct {
+    double glMatrix[16]; int templateId; int markerId; double score; float square[8]; double aspectRatio;
+} OcvarMarker;
+
+/* Pre-dedupe candidate (one per frame-pass quad with a crop-pass quad, per template); SURVEY.md 8(d). */
+typedef struct {
+    int markerId, templateId, orient, valid;
+    long long bit;
+    float square[8];
+    float patPoint[8];
+} OcvarCandidate;
+
+typedef struct OcvarHip OcvarHip;
+
+enum {
+    OCVAR_OK = 0,
+    OCVAR_E_NO_DEVICE = -1,   /* no HIP device / not gfx950 */
+    OCVAR_E_ARG = -2,
+    OCVAR_E_HIP = -3,         /* a HIP runtime call failed; see ocvar_hip_last_error */
+    OCVAR_E_CAPACITY = -4     /* a device work list overflowed (frame too cluttered for the configured limits) */
+};
+
+enum { OCVAR_MAX_TEMPLATES = 16, OCVAR_MAX_QUADS = 256, OCVAR_MAX_MARKERS = 64 };
+
+/* Creates a context on `device` with workspace for batches of up to max_batch frames of up to
+ * max_width x max_height pixels. */
+int ocvar_hip_create(OcvarHip** ctx, int device, int max_width, int max_height, int max_batch);
+void ocvar_hip_destroy(OcvarHip* ctx);
+const char* ocvar_hip_last_error(const OcvarHip* ctx);
+
+int ocvar_hip_set_templates(OcvarHip* ctx, const OcvarTemplate* templates, int n);
+int ocvar_hip_set_camera(OcvarHip* ctx, const OcvarCamera* camera);
+
+/* Batch detection on frames already resident in device memory.
+ *   d_bgr        8UC3 interleaved BGR, frame f starts at d_bgr + f*frame_stride, rows row_stride bytes apart
+ *   grey_in_place non-zero: overwrite each frame with its grey version (the reference's side effect,
+ *                opencvar.cpp:624-627)
+ *   prev / prev_counts  host arrays [n_frames][OCVAR_MAX_MARKERS] and [n_frames] of the previous call's
+ *                markers per stream, or NULL for stateless detection
+ *   markers / counts    host outputs [n_frames][max_per_frame] and [n_frames]; counts[f] is the reference's
+ *                return value for frame f (may exceed max_per_frame; only the first max_per_frame are stored)
+ * ocvar_hip_detect_device = enqueue + wait + copy-out.  The enqueue/collect pair lets a caller time or
+ * overlap the device work; `stream` is a hipStream_t (NULL = the context's own stream). */
+int ocvar_hip_detect_device(OcvarHip* ctx, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                            int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts,
+                            OcvarMarker* markers, int* counts, int max_per_frame);
+int ocvar_hip_enqueue(OcvarHip* ctx, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                      int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts, void* stream);
+int ocvar_hip_collect(OcvarHip* ctx, OcvarMarker* markers, int* counts, int max_per_frame);
+
+/* Same, frames in host memory (copied over PCIe first; greyed frames are copied back when requested). */
+int ocvar_hip_detect_host(OcvarHip* ctx, uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,
+                          int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts,
+                          OcvarMarker* markers, int* counts, int max_per_frame);
+
+/* cvarFindSquares on one 8-bit single-channel host image (the reference runs it on grey 3-channel images
+ * whose channels are equal).  quads: up to max_quads x 8 ints in the reference's sequence order. */
+int ocvar_hip_find_squares(OcvarHip* ctx, const uint8_t* h_gray, int width, int height, int row_stride, int* quads,
+                           int max_quads, int* n_quads);
+
+/* Parity hooks on the state left by the last detect/enqueue+collect call. */
+int ocvar_hip_debug_gray(OcvarHip* ctx, int frame, uint8_t* h_gray /* width*height */);
+int ocvar_hip_debug_binary(OcvarHip* ctx, int frame, uint8_t* h_bin /* (w&~1)*(h&~1), values 0/255 */);
+int ocvar_hip_debug_frame_quads(OcvarHip* ctx, int frame, int* quads /* OCVAR_MAX_QUADS*8 */, int* n_quads);
+int ocvar_hip_debug_candidates(OcvarHip* ctx, int frame, OcvarCandidate* cands, int max_cands, int* n_cands);
+
+/* Per-stage device time of the last enqueue in milliseconds (HIP events on the launch stream):
+ * [0] binarise(frame) [1] follow+approx(frame) [2] order/crops [3] binarise(crops) [4] follow+approx(crops)
+ * [5] decode [6] dedupe+pose [7] whole batch.  Returns the number of entries written. */
+int ocvar_hip_stage_ms(OcvarHip* ctx, float* ms, int n);
+/* Work counters of the last batch: [0] frame start candidates [1] crop ROIs [2] crop tiles
+ * [3] crop start candidates [4] sum of crop areas (pixels) [5] point-pool ints used. */
+int ocvar_hip_counters(OcvarHip* ctx, long long* out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,223 @@
+"""MI355X-native AR-marker detection path of youtalk/opencv-ar -- Python binding of the C ABI.
+
+The product is `lib/libocvar_hip.so` (hand-written HIP kernels for gfx950 behind `include/ocvar_hip.h`) and
+`lib/libopencv-ar.so` (the host C++ mirror of the reference's `include/opencvar` API).  This module only binds
+the C ABI with ctypes so that tests, `bench.py` and Python callers can drive it; torch is used by callers for
+device memory and `torch.distributed`, never for compute.  There is no CPU fallback: importing works without a
+GPU (so the symbol table can be checked), creating a `Detector` does not.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+HIP_LIB = os.path.join(LIB_DIR, "libocvar_hip.so")
+SYNTH_LIB = os.path.join(LIB_DIR, "libocvar_synth.so")
+HOST_LIB = os.path.join(LIB_DIR, "libopencv-ar.so.1.0.0")
+
+MAX_TEMPLATES, MAX_QUADS, MAX_MARKERS = 16, 256, 64
+
+# every symbol include/ocvar_hip.h declares
+HIP_SYMBOLS = [
+    "ocvar_hip_create", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
+    "ocvar_hip_detect_device", "ocvar_hip_enqueue", "ocvar_hip_collect", "ocvar_hip_detect_host", "ocvar_hip_find_squares",
+    "ocvar_hip_debug_gray", "ocvar_hip_debug_binary", "ocvar_hip_debug_frame_quads", "ocvar_hip_debug_candidates",
+    "ocvar_hip_stage_ms", "ocvar_hip_counters",
+]
+
+
+class Camera(C.Structure):  # CvarCamera, reference include/opencvar/opencvar.h:54-60
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("cameraMatrix", C.c_double * 9),
+                ("distCoeffs", C.c_double * 5), ("glProjection", C.c_double * 16)]
+
+
+class Template(C.Structure):  # CvarTemplate, opencvar.h:65-70
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("scale", C.c_double), ("code", C.c_longlong * 4)]
+
+
+class Marker(C.Structure):  # CvarMarker, opencvar.h:75-82
+    _fields_ = [("glMatrix", C.c_double * 16), ("templateId", C.c_int), ("markerId", C.c_int),
+                ("score", C.c_double), ("square", C.c_float * 8), ("aspectRatio", C.c_double)]
+
+
+class Candidate(C.Structure):
+    _fields_ = [("markerId", C.c_int), ("templateId", C.c_int), ("orient", C.c_int), ("valid", C.c_int),
+                ("bit", C.c_longlong), ("square", C.c_float * 8), ("patPoint", C.c_float * 8)]
+
+
+MARKER_DTYPE = np.dtype([("glMatrix", "<f8", (16,)), ("templateId", "<i4"), ("markerId", "<i4"), ("score", "<f8"),
+                         ("square", "<f4", (8,)), ("aspectRatio", "<f8")], align=True)
+assert C.sizeof(Camera) == 248 and C.sizeof(Template) == 48 and C.sizeof(Marker) == 184 and MARKER_DTYPE.itemsize == 184
+
+
+class OcvarError(RuntimeError):
+    pass
+
+
+_hip = None
+
+
+def hip_lib():
+    """Loads the HIP library; raises if it has not been built (no silent fallback)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB):
+            raise OcvarError(f"{HIP_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback for the detection path)")
+        lib = C.CDLL(HIP_LIB)
+        vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+        lib.ocvar_hip_create.argtypes = [C.POINTER(vp), i, i, i, i]
+        lib.ocvar_hip_destroy.argtypes = [vp]
+        lib.ocvar_hip_destroy.restype = None
+        lib.ocvar_hip_last_error.argtypes = [vp]
+        lib.ocvar_hip_last_error.restype = C.c_char_p
+        lib.ocvar_hip_set_templates.argtypes = [vp, vp, i]
+        lib.ocvar_hip_set_camera.argtypes = [vp, vp]
+        lib.ocvar_hip_detect_device.argtypes = [vp, vp, i, i, i, sz, i, i, vp, vp, vp, vp, i]
+        lib.ocvar_hip_enqueue.argtypes = [vp, vp, i, i, i, sz, i, i, vp, vp, vp]
+        lib.ocvar_hip_collect.argtypes = [vp, vp, vp, i]
+        lib.ocvar_hip_detect_host.argtypes = [vp, vp, i, i, i, sz, i, i, vp, vp, vp, vp, i]
+        lib.ocvar_hip_find_squares.argtypes = [vp, vp, i, i, i, vp, i, vp]
+        lib.ocvar_hip_debug_gray.argtypes = [vp, i, vp]
+        lib.ocvar_hip_debug_binary.argtypes = [vp, i, vp]
+        lib.ocvar_hip_debug_frame_quads.argtypes = [vp, i, vp, vp]
+        lib.ocvar_hip_debug_candidates.argtypes = [vp, i, vp, i, vp]
+        lib.ocvar_hip_stage_ms.argtypes = [vp, vp, i]
+        lib.ocvar_hip_counters.argtypes = [vp, vp, i]
+        _hip = lib
+    return _hip
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class Detector:
+    """A device context: batches of frames -> CvarMarker arrays (cvarArMultRegistration semantics per frame)."""
+
+    def __init__(self, max_width, max_height, max_batch=1, device=0):
+        self._lib = hip_lib()
+        self._ctx = C.c_void_p()
+        rc = self._lib.ocvar_hip_create(C.byref(self._ctx), device, max_width, max_height, max_batch)
+        if rc != 0:
+            msg = self._lib.ocvar_hip_last_error(self._ctx).decode() if self._ctx else "no gfx950 device"
+            if self._ctx:
+                self._lib.ocvar_hip_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+            raise OcvarError(f"ocvar_hip_create failed ({rc}): {msg}")
+        self.max_batch = max_batch
+        self.n_templates = 0
+
+    def close(self):
+        if self._ctx:
+            self._lib.ocvar_hip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise OcvarError(f"{what} failed ({rc}): {self._lib.ocvar_hip_last_error(self._ctx).decode()}")
+
+    def set_templates(self, templates):
+        arr = (Template * len(templates))(*templates)
+        self._check(self._lib.ocvar_hip_set_templates(self._ctx, arr, len(templates)), "set_templates")
+        self.n_templates = len(templates)
+
+    def set_camera(self, camera):
+        self._check(self._lib.ocvar_hip_set_camera(self._ctx, C.byref(camera)), "set_camera")
+
+    @staticmethod
+    def _prev_arrays(prev, n_frames):
+        if prev is None:
+            return None, None
+        pm = np.zeros((n_frames, MAX_MARKERS), MARKER_DTYPE)
+        pc = np.zeros(n_frames, np.int32)
+        for f, lst in enumerate(prev):
+            pc[f] = min(len(lst), MAX_MARKERS)
+            for k in range(pc[f]):
+                pm[f, k] = lst[k]
+        return pm, pc
+
+    def enqueue_device(self, d_ptr, width, height, n_frames, row_stride=None, frame_stride=None, grey_in_place=False,
+                       prev=None, stream=None):
+        row_stride = row_stride or 3 * width
+        frame_stride = frame_stride or row_stride * height
+        pm, pc = self._prev_arrays(prev, n_frames)
+        self._keep = (pm, pc)
+        self._check(self._lib.ocvar_hip_enqueue(self._ctx, d_ptr, width, height, row_stride, frame_stride, n_frames,
+                                                int(grey_in_place), _ptr(pm), _ptr(pc), stream), "enqueue")
+        self._n = n_frames
+
+    def collect(self, max_per_frame=MAX_MARKERS):
+        n = self._n
+        markers = np.zeros((n, max_per_frame), MARKER_DTYPE)
+        counts = np.zeros(n, np.int32)
+        self._check(self._lib.ocvar_hip_collect(self._ctx, _ptr(markers), _ptr(counts), max_per_frame), "collect")
+        return markers, counts
+
+    def detect_device(self, d_ptr, width, height, n_frames, **kw):
+        max_per_frame = kw.pop("max_per_frame", MAX_MARKERS)
+        self.enqueue_device(d_ptr, width, height, n_frames, **kw)
+        return self.collect(max_per_frame)
+
+    def detect_host(self, frames, grey_in_place=False, prev=None, max_per_frame=MAX_MARKERS):
+        """frames: uint8 array [n, H, W, 3] (C-contiguous).  Greyed in place when asked (reference side effect)."""
+        assert frames.dtype == np.uint8 and frames.ndim == 4 and frames.shape[3] == 3 and frames.flags.c_contiguous
+        n, h, w, _ = frames.shape
+        markers = np.zeros((n, max_per_frame), MARKER_DTYPE)
+        counts = np.zeros(n, np.int32)
+        pm, pc = self._prev_arrays(prev, n)
+        self._check(self._lib.ocvar_hip_detect_host(self._ctx, _ptr(frames), w, h, 3 * w, 3 * w * h, n, int(grey_in_place),
+                                                    _ptr(pm), _ptr(pc), _ptr(markers), _ptr(counts), max_per_frame),
+                    "detect_host")
+        self._n = n
+        return markers, counts
+
+    def find_squares(self, gray):
+        g = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = g.shape
+        quads = np.zeros((MAX_QUADS, 4, 2), np.int32)
+        n = C.c_int(0)
+        self._check(self._lib.ocvar_hip_find_squares(self._ctx, _ptr(g), w, h, w, _ptr(quads), MAX_QUADS, C.byref(n)),
+                    "find_squares")
+        return quads[:min(n.value, MAX_QUADS)].copy(), n.value
+
+    # parity hooks
+    def debug_gray(self, frame, width, height):
+        out = np.zeros((height, width), np.uint8)
+        self._check(self._lib.ocvar_hip_debug_gray(self._ctx, frame, _ptr(out)), "debug_gray")
+        return out
+
+    def debug_binary(self, frame, width, height):
+        out = np.zeros((height & -2, width & -2), np.uint8)
+        self._check(self._lib.ocvar_hip_debug_binary(self._ctx, frame, _ptr(out)), "debug_binary")
+        return out
+
+    def debug_frame_quads(self, frame):
+        quads = np.zeros((MAX_QUADS, 4, 2), np.int32)
+        n = C.c_int(0)
+        self._check(self._lib.ocvar_hip_debug_frame_quads(self._ctx, frame, _ptr(quads), C.byref(n)), "debug_frame_quads")
+        return quads[:min(n.value, MAX_QUADS)].copy()
+
+    def debug_candidates(self, frame, max_cands=MAX_QUADS * MAX_TEMPLATES):
+        arr = (Candidate * max_cands)()
+        n = C.c_int(0)
+        self._check(self._lib.ocvar_hip_debug_candidates(self._ctx, frame, arr, max_cands, C.byref(n)), "debug_candidates")
+        return [arr[i] for i in range(min(n.value, max_cands))]
+
+    def stage_ms(self):
+        ms = np.zeros(8, np.float32)
+        k = self._lib.ocvar_hip_stage_ms(self._ctx, _ptr(ms), 8)
+        return ms[:max(k, 0)]
+
+    def counters(self):
+        out = np.zeros(6, np.int64)
+        k = self._lib.ocvar_hip_counters(self._ctx, _ptr(out), 6)
+        return out[:max(k, 0)]

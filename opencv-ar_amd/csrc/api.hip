@@ -1,0 +1,398 @@
+// api.hip -- the thin C ABI of include/ocvar_hip.h: context, device workspace, launch sequence, result copy-out.
+//
+// One batch = 7 kernel launches on one HIP stream, no host round trip in between (work counts stay in
+// device memory and the second-pass kernels are launched with fixed grids that read them):
+//   binarise(frames) -> follow(frames) -> order+crops -> binarise(crops) -> follow(crops) -> decode -> finalise
+// There is deliberately no CPU path here: if the device or the code object is missing, create() fails.
+#include "kernels.h"
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace ocvar;
+
+static_assert(sizeof(TemplateRec) == sizeof(OcvarTemplate) && sizeof(TemplateRec) == 48, "CvarTemplate layout");
+static_assert(sizeof(CameraRec) == sizeof(OcvarCamera) && sizeof(CameraRec) == 248, "CvarCamera layout");
+static_assert(sizeof(MarkerRec) == sizeof(OcvarMarker) && sizeof(MarkerRec) == 184, "CvarMarker layout");
+
+struct OcvarHip {
+    int device = 0;
+    Workspace ws{};
+    hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev[9]{};
+    std::vector<void*> allocs;
+    uint8_t* d_frames = nullptr;  // staging for the host-buffer entry points
+    size_t d_frames_bytes = 0;
+    MarkerRec* h_markers = nullptr;  // pinned
+    int* h_counts = nullptr;         // pinned
+    int* h_counters = nullptr;       // pinned
+    bool pending = false;
+    bool have_templates = false, have_camera = false;
+    std::string err;
+};
+
+#define HIP_TRY(ctx, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            return OCVAR_E_HIP;                                                                         \
+        }                                                                                               \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(OcvarHip* c, T** p, size_t n) {
+    void* q = nullptr;
+    HIP_TRY(c, hipMalloc(&q, n * sizeof(T) + 256));
+    c->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int max_height, int max_batch) {
+    if (!out || max_width < 16 || max_height < 16 || max_batch < 1) return OCVAR_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return OCVAR_E_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return OCVAR_E_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "ocvar_hip: device %d is %s; this library carries gfx950 code only\n", device, prop.gcnArchName);
+        return OCVAR_E_NO_DEVICE;
+    }
+    OcvarHip* c = new (std::nothrow) OcvarHip();
+    if (!c) return OCVAR_E_HIP;
+    *out = c;  // returned even on failure below so the caller can read the error text, then destroy
+    c->device = device;
+    HIP_TRY(c, hipSetDevice(device));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
+    Workspace& w = c->ws;
+    w.max_w = max_width;
+    w.max_h = max_height;
+    w.max_batch = max_batch;
+    const size_t B = (size_t)max_batch, WH = (size_t)max_width * max_height;
+    size_t per_frame_cands = WH / 16 < 16384 ? 16384 : WH / 16;
+    w.cap_frame_cands = (int)std::min<size_t>(B * per_frame_cands, (size_t)1 << 30);
+    w.cap_crop_cands = w.cap_frame_cands;
+    w.cap_crop_rois = (int)(B * MAXQ);
+    w.cap_crop_tiles = (int)std::min<size_t>(B * 4096, (size_t)1 << 30);
+    w.cap_crop_quads = (int)(B * MAXQ * 4);
+    w.cap_pool_ints = (long long)B * (1 << 20);
+    w.cap_crop_pixels = (long long)(2 * B * WH);
+    int rc;
+    if ((rc = dev_alloc(c, &w.gray, B * WH))) return rc;
+    if ((rc = dev_alloc(c, &w.nbr_frame, B * WH))) return rc;
+    if ((rc = dev_alloc(c, &w.nbr_crop, (size_t)w.cap_crop_pixels))) return rc;
+    if ((rc = dev_alloc(c, &w.cands_frame, (size_t)w.cap_frame_cands))) return rc;
+    if ((rc = dev_alloc(c, &w.cands_crop, (size_t)w.cap_crop_cands))) return rc;
+    if ((rc = dev_alloc(c, &w.pool, (size_t)w.cap_pool_ints))) return rc;
+    if ((rc = dev_alloc(c, &w.quads_frame, B * MAXQ))) return rc;
+    if ((rc = dev_alloc(c, &w.n_quads_frame, B))) return rc;
+    if ((rc = dev_alloc(c, &w.squares, B * MAXQ * 8))) return rc;
+    if ((rc = dev_alloc(c, &w.n_squares, B))) return rc;
+    if ((rc = dev_alloc(c, &w.crop_of, B * MAXQ))) return rc;
+    if ((rc = dev_alloc(c, &w.rois_crop, (size_t)w.cap_crop_rois))) return rc;
+    if ((rc = dev_alloc(c, &w.tiles_crop, (size_t)w.cap_crop_tiles))) return rc;
+    if ((rc = dev_alloc(c, &w.quads_crop, (size_t)w.cap_crop_quads))) return rc;
+    if ((rc = dev_alloc(c, &w.best_crop, (size_t)w.cap_crop_rois))) return rc;
+    if ((rc = dev_alloc(c, &w.cand_recs, B * MAXQ * MAXT))) return rc;
+    if ((rc = dev_alloc(c, &w.prev, B * MAXM))) return rc;
+    if ((rc = dev_alloc(c, &w.n_prev, B))) return rc;
+    if ((rc = dev_alloc(c, &w.reserve, B * MAXM))) return rc;
+    if ((rc = dev_alloc(c, &w.n_reserve, B))) return rc;
+    if ((rc = dev_alloc(c, &w.markers, B * MAXM))) return rc;
+    if ((rc = dev_alloc(c, &w.n_markers, B))) return rc;
+    if ((rc = dev_alloc(c, &w.templates, (size_t)MAXT))) return rc;
+    if ((rc = dev_alloc(c, &w.camera, (size_t)1))) return rc;
+    if ((rc = dev_alloc(c, &w.counters, (size_t)CNT_COUNT))) return rc;
+    w.crop_pixels = reinterpret_cast<unsigned long long*>(w.counters + CNT_CROP_PIXELS);
+    HIP_TRY(c, hipMemset(w.n_prev, 0, B * sizeof(int)));
+    HIP_TRY(c, hipMemset(w.counters, 0, CNT_COUNT * sizeof(int)));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_markers, B * MAXM * sizeof(MarkerRec)));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_counts, B * sizeof(int)));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_counters, CNT_COUNT * sizeof(int)));
+    return OCVAR_OK;
+}
+
+extern "C" void ocvar_hip_destroy(OcvarHip* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->d_frames) (void)hipFree(c->d_frames);
+    if (c->h_markers) (void)hipHostFree(c->h_markers);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* ocvar_hip_last_error(const OcvarHip* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int ocvar_hip_set_templates(OcvarHip* c, const OcvarTemplate* t, int n) {
+    if (!c || !t || n < 1 || n > MAXT) return OCVAR_E_ARG;
+    for (int i = 0; i < n; i++)
+        if (t[i].width < 1 || t[i].height < 1 || t[i].width * t[i].height > 64) return OCVAR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(c->ws.templates, t, n * sizeof(OcvarTemplate), hipMemcpyHostToDevice));
+    c->ws.n_templates = n;
+    c->have_templates = true;
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_set_camera(OcvarHip* c, const OcvarCamera* cam) {
+    if (!c || !cam) return OCVAR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(c->ws.camera, cam, sizeof(OcvarCamera), hipMemcpyHostToDevice));
+    c->have_camera = true;
+    return OCVAR_OK;
+}
+
+static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride, int n_frames,
+                        int grey_in_place, const OcvarMarker* prev, const int* prev_counts, hipStream_t s, int stages) {
+    Workspace& w = c->ws;
+    if (!d_bgr || width < 16 || height < 16 || width > w.max_w || height > w.max_h || n_frames < 1 || n_frames > w.max_batch ||
+        (size_t)width * height > (size_t)w.max_w * w.max_h || row_stride < 3 * width)
+        return OCVAR_E_ARG;
+    if (stages > 2 && (!c->have_templates || !c->have_camera)) {
+        c->err = "templates and camera must be set before detection";
+        return OCVAR_E_ARG;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    w.W = width;
+    w.H = height;
+    w.sw = width & ~1;
+    w.sh = height & ~1;
+    w.n_frames = n_frames;
+    HIP_TRY(c, hipMemsetAsync(w.counters, 0, CNT_COUNT * sizeof(int), s));
+    HIP_TRY(c, hipMemsetAsync(w.n_quads_frame, 0, n_frames * sizeof(int), s));
+    if (prev && prev_counts) {
+        HIP_TRY(c, hipMemcpyAsync(w.prev, prev, (size_t)n_frames * MAXM * sizeof(MarkerRec), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(w.n_prev, prev_counts, n_frames * sizeof(int), hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(c, hipMemsetAsync(w.n_prev, 0, n_frames * sizeof(int), s));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    launch_binarise_frames(w, d_bgr, row_stride, frame_stride, grey_in_place, s);
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    launch_follow_frames(w, s);
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    launch_order_and_crops(w, s);
+    HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    if (stages > 2) {
+        launch_binarise_crops(w, s);
+        HIP_TRY(c, hipEventRecord(c->ev[4], s));
+        launch_follow_crops(w, s);
+        HIP_TRY(c, hipEventRecord(c->ev[5], s));
+        launch_decode(w, s);
+        HIP_TRY(c, hipEventRecord(c->ev[6], s));
+        launch_finalise(w, s);
+        HIP_TRY(c, hipEventRecord(c->ev[7], s));
+        HIP_TRY(c, hipMemcpyAsync(c->h_counts, w.n_markers, n_frames * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(c->h_markers, w.markers, (size_t)n_frames * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToHost, s));
+    } else {
+        for (int k = 4; k < 8; k++) HIP_TRY(c, hipEventRecord(c->ev[k], s));
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, w.counters, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(c->ev[8], s));
+    HIP_TRY(c, hipGetLastError());
+    c->last_stream = s;
+    c->pending = true;
+    return OCVAR_OK;
+}
+
+static int wait_impl(OcvarHip* c) {
+    if (!c->pending) {
+        c->err = "nothing enqueued";
+        return OCVAR_E_ARG;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->last_stream));
+    c->pending = false;
+    const int e = c->h_counters[CNT_ERR];
+    if (e) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "device work list overflow / trace overrun, flags 0x%x (1 starts, 2 point pool, 4 quads, 8 overrun, 16 crops, 32 tiles)", e);
+        c->err = buf;
+        return OCVAR_E_CAPACITY;
+    }
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_enqueue(OcvarHip* c, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                 int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts, void* stream) {
+    if (!c) return OCVAR_E_ARG;
+    return enqueue_impl(c, d_bgr, width, height, row_stride, frame_stride, n_frames, grey_in_place, prev, prev_counts,
+                        stream ? (hipStream_t)stream : c->stream, 3);
+}
+
+extern "C" int ocvar_hip_collect(OcvarHip* c, OcvarMarker* markers, int* counts, int max_per_frame) {
+    if (!c || !counts || max_per_frame < 0 || (max_per_frame > 0 && !markers)) return OCVAR_E_ARG;
+    int rc = wait_impl(c);
+    if (rc) return rc;
+    const int n = c->ws.n_frames;
+    for (int f = 0; f < n; f++) {
+        counts[f] = c->h_counts[f];
+        int k = counts[f] < max_per_frame ? counts[f] : max_per_frame;
+        if (k > MAXM) k = MAXM;
+        if (k > 0) std::memcpy(markers + (size_t)f * max_per_frame, c->h_markers + (size_t)f * MAXM, k * sizeof(OcvarMarker));
+    }
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_detect_device(OcvarHip* c, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                       int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts,
+                                       OcvarMarker* markers, int* counts, int max_per_frame) {
+    int rc = ocvar_hip_enqueue(c, d_bgr, width, height, row_stride, frame_stride, n_frames, grey_in_place, prev, prev_counts, nullptr);
+    if (rc) return rc;
+    return ocvar_hip_collect(c, markers, counts, max_per_frame);
+}
+
+static int stage_frames(OcvarHip* c, const uint8_t* h, int height, int row_stride, size_t frame_stride, int n_frames) {
+    const size_t bytes = (size_t)(n_frames - 1) * frame_stride + (size_t)height * row_stride;
+    if (bytes > c->d_frames_bytes) {
+        if (c->d_frames) (void)hipFree(c->d_frames);
+        c->d_frames = nullptr;
+        c->d_frames_bytes = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_frames, bytes));
+        c->d_frames_bytes = bytes;
+    }
+    HIP_TRY(c, hipMemcpy(c->d_frames, h, bytes, hipMemcpyHostToDevice));
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                     int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts,
+                                     OcvarMarker* markers, int* counts, int max_per_frame) {
+    if (!c || !h_bgr || n_frames < 1 || height < 1 || row_stride < 1) return OCVAR_E_ARG;
+    if (n_frames > 1 && frame_stride < (size_t)height * row_stride) return OCVAR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = stage_frames(c, h_bgr, height, row_stride, frame_stride, n_frames);
+    if (rc) return rc;
+    rc = ocvar_hip_detect_device(c, c->d_frames, width, height, row_stride, frame_stride, n_frames, grey_in_place, prev,
+                                 prev_counts, markers, counts, max_per_frame);
+    if (rc) return rc;
+    if (grey_in_place) {
+        const size_t bytes = (size_t)(n_frames - 1) * frame_stride + (size_t)height * row_stride;
+        HIP_TRY(c, hipMemcpy(h_bgr, c->d_frames, bytes, hipMemcpyDeviceToHost));
+    }
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_find_squares(OcvarHip* c, const uint8_t* h_gray, int width, int height, int row_stride, int* quads,
+                                      int max_quads, int* n_quads) {
+    if (!c || !h_gray || !quads || !n_quads || width < 16 || height < 16 || row_stride < width) return OCVAR_E_ARG;
+    std::vector<uint8_t> bgr((size_t)width * height * 3);
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const uint8_t g = h_gray[(size_t)y * row_stride + x];
+            uint8_t* p = &bgr[((size_t)y * width + x) * 3];
+            p[0] = p[1] = p[2] = g;  // grey of an equal-channel pixel is the pixel
+        }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = stage_frames(c, bgr.data(), height, width * 3, (size_t)width * height * 3, 1);
+    if (rc) return rc;
+    rc = enqueue_impl(c, c->d_frames, width, height, width * 3, (size_t)width * height * 3, 1, 0, nullptr, nullptr, c->stream, 2);
+    if (rc) return rc;
+    rc = wait_impl(c);
+    if (rc) return rc;
+    int n = 0;
+    HIP_TRY(c, hipMemcpy(&n, c->ws.n_squares, sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<float> sq((size_t)MAXQ * 8);
+    HIP_TRY(c, hipMemcpy(sq.data(), c->ws.squares, sq.size() * sizeof(float), hipMemcpyDeviceToHost));
+    *n_quads = n;
+    for (int i = 0; i < n && i < max_quads; i++)
+        for (int k = 0; k < 8; k++) quads[8 * i + k] = (int)sq[8 * (size_t)i + k];
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_debug_gray(OcvarHip* c, int frame, uint8_t* h) {
+    if (!c || !h || frame < 0 || frame >= c->ws.n_frames) return OCVAR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t wh = (size_t)c->ws.W * c->ws.H;
+    HIP_TRY(c, hipMemcpy(h, c->ws.gray + frame * wh, wh, hipMemcpyDeviceToHost));
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_debug_binary(OcvarHip* c, int frame, uint8_t* h) {
+    if (!c || !h || frame < 0 || frame >= c->ws.n_frames) return OCVAR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int sw = c->ws.sw, sh = c->ws.sh;
+    std::vector<uint8_t> nbr((size_t)sw * sh);
+    HIP_TRY(c, hipMemcpy(nbr.data(), c->ws.nbr_frame + (size_t)frame * sw * sh, nbr.size(), hipMemcpyDeviceToHost));
+    // pixel (x,y) is the west neighbour (bit 4) of (x+1,y); the 1-px frame is zero as cvFindContours makes it
+    for (int y = 0; y < sh; y++)
+        for (int x = 0; x < sw; x++) h[(size_t)y * sw + x] = (x + 1 < sw && ((nbr[(size_t)y * sw + x + 1] >> 4) & 1)) ? 255 : 0;
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_debug_frame_quads(OcvarHip* c, int frame, int* quads, int* n_quads) {
+    if (!c || !quads || !n_quads || frame < 0 || frame >= c->ws.n_frames) return OCVAR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int n = 0;
+    HIP_TRY(c, hipMemcpy(&n, c->ws.n_squares + frame, sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<float> sq((size_t)MAXQ * 8);
+    HIP_TRY(c, hipMemcpy(sq.data(), c->ws.squares + (size_t)frame * MAXQ * 8, sq.size() * sizeof(float), hipMemcpyDeviceToHost));
+    *n_quads = n;
+    for (int i = 0; i < n && i < MAXQ; i++)
+        for (int k = 0; k < 8; k++) quads[8 * i + k] = (int)sq[8 * (size_t)i + k];
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_debug_candidates(OcvarHip* c, int frame, OcvarCandidate* cands, int max_cands, int* n_cands) {
+    if (!c || !cands || !n_cands || frame < 0 || frame >= c->ws.n_frames) return OCVAR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int nsq = 0;
+    HIP_TRY(c, hipMemcpy(&nsq, c->ws.n_squares + frame, sizeof(int), hipMemcpyDeviceToHost));
+    if (nsq > MAXQ) nsq = MAXQ;
+    std::vector<CandRec> recs((size_t)MAXQ * MAXT);
+    HIP_TRY(c, hipMemcpy(recs.data(), c->ws.cand_recs + (size_t)frame * MAXQ * MAXT, recs.size() * sizeof(CandRec), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int i = 0; i < nsq; i++)
+        for (int j = 0; j < c->ws.n_templates; j++) {
+            const CandRec& r = recs[(size_t)i * MAXT + j];
+            if (!r.valid) continue;
+            if (n < max_cands) {
+                OcvarCandidate& o = cands[n];
+                o.markerId = i;
+                o.templateId = j;
+                o.orient = r.orient;
+                o.valid = 1;
+                o.bit = r.bit;
+                std::memcpy(o.square, r.square, sizeof o.square);
+                std::memcpy(o.patPoint, r.patPoint, sizeof o.patPoint);
+            }
+            n++;
+        }
+    *n_cands = n;
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_stage_ms(OcvarHip* c, float* ms, int n) {
+    if (!c || !ms || n < 1 || c->pending) return OCVAR_E_ARG;
+    int k = 0;
+    for (; k < 7 && k < n; k++)
+        if (hipEventElapsedTime(&ms[k], c->ev[k], c->ev[k + 1]) != hipSuccess) ms[k] = -1.f;
+    if (k < n && k == 7) {
+        if (hipEventElapsedTime(&ms[7], c->ev[0], c->ev[8]) != hipSuccess) ms[7] = -1.f;
+        k = 8;
+    }
+    return k;
+}
+
+extern "C" int ocvar_hip_counters(OcvarHip* c, long long* out, int n) {
+    if (!c || !out || n < 1 || c->pending) return OCVAR_E_ARG;
+    const int* h = c->h_counters;
+    long long v[6] = {h[CNT_FRAME_CANDS], h[CNT_CROP_ROIS], h[CNT_CROP_TILES], h[CNT_CROP_CANDS],
+                      (long long)*reinterpret_cast<const unsigned long long*>(h + CNT_CROP_PIXELS),
+                      (long long)*reinterpret_cast<const unsigned long long*>(h + CNT_POOL_INTS)};
+    int k = 0;
+    for (; k < 6 && k < n; k++) out[k] = v[k];
+    return k;
+}

@@ -1,0 +1,52 @@
+// hd.h -- shared definitions for the HIP kernels (gfx950) of the opencv-ar hot path.
+//
+// The algorithm cores in *_core.h are written as plain functions so that tests/emul can compile them
+// with g++ and check their logic against the oracle without a GPU.  That host build is test-only;
+// the product library (libocvar_hip.so) contains the gfx950 code objects and nothing else computes.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define OCVAR_HD __host__ __device__ __forceinline__
+#define OCVAR_D __device__ __forceinline__
+#else
+#define OCVAR_HD inline
+#define OCVAR_D inline
+#endif
+
+namespace ocvar {
+
+// Pixel-neighbour directions of the border follower, s = 0..7 = E,NE,N,NW,W,SW,S,SE
+// (increasing s is counter-clockwise on screen; cvFindContours' icvCodeDeltas order).
+OCVAR_HD int dir_dx(int s) { return (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0); }
+OCVAR_HD int dir_dy(int s) { return (s >= 1 && s <= 3) ? -1 : ((s >= 5 && s <= 7) ? 1 : 0); }
+
+struct Pt { int x, y; };
+
+// One region of interest handed to the square finder: a whole frame (frame pass) or the clipped
+// bounding box of a frame-pass quad (crop pass, opencvar.cpp:682-693).
+struct Roi {
+    int frame;        // frame index in the batch
+    int x0, y0;       // origin inside the frame's gray plane
+    int w, h;         // ROI size (img->width/height for the border rule, opencvar.cpp:204-206)
+    int sw, sh;       // w & ~1, h & ~1 (opencvar.cpp:158): size of the binary / neighbour plane
+    int owner;        // frame pass: frame index; crop pass: index of the frame-pass quad it came from
+    long long nbr_off;  // offset of this ROI's neighbour-mask plane in the pass's pool
+};
+
+// A candidate border start found by the binarise kernel.
+struct StartCand {
+    int roi;
+    int pos;          // scan position y*sw + x at which cvFindContours would discover the border
+    int is_hole;
+};
+
+// A quad that passed the cvarFindSquares filter.
+struct QuadRec {
+    int roi;
+    int start;        // discovery scan position (orders the sequence: later discovery = earlier in list)
+    int pt[8];
+};
+
+}  // namespace ocvar

@@ -1,0 +1,81 @@
+// kernels.h -- device workspace layout and launch entry points shared by the .hip translation units.
+#pragma once
+#include "hd.h"
+#include "decode_core.h"
+#include "pose_core.h"
+#include "tail_core.h"
+#include "ocvar_hip.h"
+
+namespace ocvar {
+
+constexpr int MAXQ = OCVAR_MAX_QUADS;      // frame-pass quads kept per frame
+constexpr int MAXM = OCVAR_MAX_MARKERS;    // markers kept per frame (tracked + new)
+constexpr int MAXT = OCVAR_MAX_TEMPLATES;
+constexpr int TILE_W = 64, TILE_H = 32;    // output tile of the binarise kernel
+constexpr int BACK_STEPS = 32;             // backward look of an outer start before it follows its border
+
+// error bits accumulated in Workspace::err[0]
+enum { ERR_CAND_OVERFLOW = 1, ERR_POOL_OVERFLOW = 2, ERR_QUAD_OVERFLOW = 4, ERR_TRACE_OVERRUN = 8, ERR_CROP_OVERFLOW = 16,
+       ERR_TILE_OVERFLOW = 32 };
+
+struct TileDesc { int roi, x0, y0; };
+
+struct CandRec {   // pre-dedupe candidate, slot [frame][quad][template]
+    int valid, orient;
+    long long bit;
+    float square[8];
+    float patPoint[8];
+};
+
+// counters block (device ints), zeroed at the start of every batch
+enum { CNT_FRAME_CANDS = 0, CNT_CROP_ROIS = 1, CNT_CROP_TILES = 2, CNT_CROP_CANDS = 3,
+       CNT_POOL_INTS = 4 /* 64-bit, uses 4..5 */, CNT_CROP_QUADS = 6, CNT_TICKET_F = 7, CNT_TICKET_C = 8, CNT_ERR = 9,
+       CNT_CROP_PIXELS = 10 /* 64-bit, uses 10..11 */, CNT_COUNT = 16 };
+
+struct Workspace {
+    // limits
+    int max_w, max_h, max_batch;
+    int cap_frame_cands, cap_crop_cands, cap_crop_rois, cap_crop_tiles, cap_crop_quads;
+    long long cap_pool_ints, cap_crop_pixels;
+    // per batch geometry
+    int W, H, sw, sh, n_frames, n_templates;
+    // device buffers
+    uint8_t* gray;          // [B][H][W]
+    uint8_t* nbr_frame;     // [B][sh][sw]
+    uint8_t* nbr_crop;      // crop pool
+    StartCand* cands_frame;
+    StartCand* cands_crop;
+    int* pool;              // points + DP stacks
+    QuadRec* quads_frame;   // [B][MAXQ] unordered
+    int* n_quads_frame;     // [B]
+    float* squares;         // [B][MAXQ][8] ordered, after tracking
+    int* n_squares;         // [B]
+    int* crop_of;           // [B][MAXQ] crop ROI index of square i, or -1
+    Roi* rois_crop;
+    TileDesc* tiles_crop;
+    unsigned long long* crop_pixels;   // = counters + CNT_CROP_PIXELS: running sum of crop plane sizes (pool cursor)
+    QuadRec* quads_crop;    // pool
+    unsigned long long* best_crop;     // [cap_crop_rois] (start<<32 | quad slot), ~0 = none
+    CandRec* cand_recs;     // [B][MAXQ][MAXT]
+    MarkerRec* prev;        // [B][MAXM]
+    int* n_prev;            // [B]
+    int* reserve;           // [B][MAXM] tracked marker indices
+    int* n_reserve;         // [B]
+    MarkerRec* markers;     // [B][MAXM] output
+    int* n_markers;         // [B]
+    TemplateRec* templates; // [MAXT]
+    CameraRec* camera;
+    int* counters;          // [CNT_COUNT]
+};
+
+// launchers (each enqueues on `stream`, no synchronisation)
+void launch_binarise_frames(const Workspace& ws, const uint8_t* d_bgr, int row_stride, size_t frame_stride, int grey_in_place,
+                            hipStream_t stream);
+void launch_binarise_crops(const Workspace& ws, hipStream_t stream);
+void launch_follow_frames(const Workspace& ws, hipStream_t stream);
+void launch_follow_crops(const Workspace& ws, hipStream_t stream);
+void launch_order_and_crops(const Workspace& ws, hipStream_t stream);
+void launch_decode(const Workspace& ws, hipStream_t stream);
+void launch_finalise(const Workspace& ws, hipStream_t stream);
+
+}  // namespace ocvar

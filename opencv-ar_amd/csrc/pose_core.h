@@ -1,0 +1,337 @@
+// pose_core.h -- planar pose of one quad -> OpenGL modelview matrix, one lane per surviving marker.
+//
+// Replaces cvarSquareToMatrix (/root/reference/src/opencvar.cpp:524-540) and what it reaches:
+// cvarSquareInit (229-245), cvarFindCamera (261-278: cvFindExtrinsicCameraParams2 + cvRodrigues2) and
+// cvarGlMatrix (133-152) with the acMatrixToQuaternion / acQuaternionToMatrix round trip
+// (/root/reference/src/acmath.cpp:215-276).
+//
+// Same estimator as OpenCV's planar branch (4-point homography -> r1,r2 normalised, r3 = r1 x r2, nearest
+// rotation, then Levenberg-Marquardt on the pixel reprojection error), written for a GPU lane: fixed-size
+// arrays, Newton iteration for the nearest rotation (no SVD), Cholesky for the 6x6 normal equations.
+// The contract is the converged minimum in the same basin (tolerance 1e-4 relative on glMatrix).
+#pragma once
+#include "hd.h"
+#include <float.h>
+#include <math.h>
+
+namespace ocvar {
+
+struct CameraRec {  // == CvarCamera (include/opencvar/opencvar.h), 248 bytes
+    int width, height;
+    double cameraMatrix[9];
+    double distCoeffs[5];
+    double glProjection[16];
+};
+
+OCVAR_HD void rodrigues(const double* r, double* R, double* J /* 3x9 or null */) {
+    double rx = r[0], ry = r[1], rz = r[2];
+    const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    if (theta < DBL_EPSILON) {
+        if (J) {
+            for (int k = 0; k < 27; k++) J[k] = 0;
+            J[5] = J[15] = J[19] = -1;
+            J[7] = J[11] = J[21] = 1;
+        }
+        return;
+    }
+    const double c = cos(theta), s = sin(theta), c1 = 1. - c, it = 1. / theta;
+    rx *= it;
+    ry *= it;
+    rz *= it;
+    const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+    const double rx_[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+    for (int k = 0; k < 9; k++) R[k] = c * R[k] + c1 * rrt[k] + s * rx_[k];
+    if (J) {
+        const double drrt[27] = {rx + rx, ry, rz, ry, 0, 0, rz, 0, 0, 0, rx, 0, rx, ry + ry, rz, 0, rz, 0,
+                                 0, 0, rx, 0, 0, ry, rx, ry, rz + rz};
+        const double drx[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 3; i++) {
+            const double ri = i == 0 ? rx : (i == 1 ? ry : rz);
+            const double a0 = -s * ri, a1 = (s - 2 * c1 * it) * ri, a2 = c1 * it, a3 = (c - s * it) * ri, a4 = s * it;
+            for (int k = 0; k < 9; k++)
+                J[i * 9 + k] = a0 * ((k % 4 == 0) ? 1.0 : 0.0) + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * rx_[k] + a4 * drx[i * 9 + k];
+        }
+    }
+}
+
+// nearest rotation (orthogonal polar factor) by Newton's iteration Q <- (Q + Q^-T)/2
+OCVAR_HD void nearest_rotation(double* Q) {
+    for (int it = 0; it < 30; it++) {
+        double C[9];
+        C[0] = Q[4] * Q[8] - Q[5] * Q[7];
+        C[1] = Q[5] * Q[6] - Q[3] * Q[8];
+        C[2] = Q[3] * Q[7] - Q[4] * Q[6];
+        C[3] = Q[2] * Q[7] - Q[1] * Q[8];
+        C[4] = Q[0] * Q[8] - Q[2] * Q[6];
+        C[5] = Q[1] * Q[6] - Q[0] * Q[7];
+        C[6] = Q[1] * Q[5] - Q[2] * Q[4];
+        C[7] = Q[2] * Q[3] - Q[0] * Q[5];
+        C[8] = Q[0] * Q[4] - Q[1] * Q[3];
+        const double det = Q[0] * C[0] + Q[1] * C[1] + Q[2] * C[2];
+        if (det == 0) return;
+        double delta = 0;
+        for (int k = 0; k < 9; k++) {
+            const double n = 0.5 * (Q[k] + C[k] / det);  // cofactor/det = inverse transpose
+            delta += (n - Q[k]) * (n - Q[k]);
+            Q[k] = n;
+        }
+        if (delta < 1e-30) break;
+    }
+}
+
+OCVAR_HD void rotation_to_rvec(const double* Rin, double* r) {
+    double R[9];
+    for (int k = 0; k < 9; k++) R[k] = Rin[k];
+    nearest_rotation(R);
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : (c < -1. ? -1. : c);
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) {
+            rx = ry = rz = 0;
+        } else {
+            double t = (R[0] + 1) * 0.5;
+            rx = sqrt(t > 0 ? t : 0);
+            t = (R[4] + 1) * 0.5;
+            ry = sqrt(t > 0 ? t : 0) * (R[1] < 0 ? -1. : 1.);
+            t = (R[8] + 1) * 0.5;
+            rz = sqrt(t > 0 ? t : 0) * (R[2] < 0 ? -1. : 1.);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta;
+            ry *= theta;
+            rz *= theta;
+        }
+    } else {
+        const double v = theta / (2 * s);
+        rx *= v;
+        ry *= v;
+        rz *= v;
+    }
+    r[0] = rx;
+    r[1] = ry;
+    r[2] = rz;
+}
+
+// homography of the marker rectangle (+-ratio, +-1) -> 4 normalised image points, exact 8x8 solve
+OCVAR_HD bool rect_homography(double ratio, const double* m, double* H) {
+    const double MX[4] = {-ratio, ratio, ratio, -ratio}, MY[4] = {-1, -1, 1, 1};
+    double A[8][9];
+    for (int i = 0; i < 4; i++) {
+        const double X = MX[i], Y = MY[i], x = m[2 * i], y = m[2 * i + 1];
+        double* a = A[2 * i];
+        double* b = A[2 * i + 1];
+        a[0] = X; a[1] = Y; a[2] = 1; a[3] = 0; a[4] = 0; a[5] = 0; a[6] = -x * X; a[7] = -x * Y; a[8] = x;
+        b[0] = 0; b[1] = 0; b[2] = 0; b[3] = X; b[4] = Y; b[5] = 1; b[6] = -y * X; b[7] = -y * Y; b[8] = y;
+    }
+    for (int c = 0; c < 8; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 8; r++)
+            if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+        if (A[piv][c] == 0) return false;
+        for (int k = 0; k < 9; k++) {
+            const double t = A[c][k];
+            A[c][k] = A[piv][k];
+            A[piv][k] = t;
+        }
+        const double inv = 1.0 / A[c][c];
+        for (int k = c; k < 9; k++) A[c][k] *= inv;
+        for (int r = 0; r < 8; r++) {
+            if (r == c) continue;
+            const double f = A[r][c];
+            if (f != 0)
+                for (int k = c; k < 9; k++) A[r][k] -= f * A[c][k];
+        }
+    }
+    for (int i = 0; i < 8; i++) H[i] = A[i][8];
+    H[8] = 1;
+    return true;
+}
+
+// reprojection of the 4 rectangle corners, residual e = proj - img, optional 8x6 Jacobian
+OCVAR_HD void reproject(double ratio, const double* p, const double* K, const double* img, double* e, double* J) {
+    double R[9], dR[27];
+    rodrigues(p, R, J ? dR : nullptr);
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double MX[4] = {-ratio, ratio, ratio, -ratio}, MY[4] = {-1, -1, 1, 1};
+    for (int i = 0; i < 4; i++) {
+        const double X = MX[i], Y = MY[i];
+        double x = R[0] * X + R[1] * Y + p[3];
+        double y = R[3] * X + R[4] * Y + p[4];
+        double z = R[6] * X + R[7] * Y + p[5];
+        z = z ? 1. / z : 1;
+        x *= z;
+        y *= z;
+        e[2 * i] = x * fx + cx - img[2 * i];
+        e[2 * i + 1] = y * fy + cy - img[2 * i + 1];
+        if (J) {
+            double* jx = J + 12 * i;
+            double* jy = jx + 6;
+            for (int j = 0; j < 3; j++) {
+                const double* d = dR + 9 * j;
+                const double dx0 = X * d[0] + Y * d[1], dy0 = X * d[3] + Y * d[4], dz0 = X * d[6] + Y * d[7];
+                jx[j] = fx * z * (dx0 - x * dz0);
+                jy[j] = fy * z * (dy0 - y * dz0);
+            }
+            jx[3] = fx * z; jx[4] = 0; jx[5] = -fx * x * z;
+            jy[3] = 0; jy[4] = fy * z; jy[5] = -fy * y * z;
+        }
+    }
+}
+
+// solves A x = b for symmetric positive definite 6x6 A (Cholesky); false if not positive definite
+OCVAR_HD bool chol6(const double* A, const double* b, double* x) {
+    double L[36];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) {
+                if (!(s > 0)) return false;
+                L[i * 6 + i] = sqrt(s);
+            } else {
+                L[i * 6 + j] = s / L[j * 6 + j];
+            }
+        }
+    double y[6];
+    for (int i = 0; i < 6; i++) {
+        double s = b[i];
+        for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k];
+        y[i] = s / L[i * 6 + i];
+    }
+    for (int i = 5; i >= 0; i--) {
+        double s = y[i];
+        for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k];
+        x[i] = s / L[i * 6 + i];
+    }
+    return true;
+}
+
+OCVAR_HD double norm_n(const double* v, int n) {
+    double s = 0;
+    for (int i = 0; i < n; i++) s += v[i] * v[i];
+    return sqrt(s);
+}
+
+OCVAR_HD void gl_from_pose(const double* R, const double* t, double* m) {
+    // cvarGlMatrix: m = R^T laid out in 4x4, through a quaternion with x,y negated, then translation.
+    for (int k = 0; k < 16; k++) m[k] = 0;
+    for (int j = 0; j < 3; j++)
+        for (int i = 0; i < 3; i++) m[i * 4 + j] = R[j * 3 + i];
+    double x, y, z, w, s;
+    const double tr = 1 + m[0] + m[5] + m[10];
+    if (tr > 0.00000001) {
+        s = sqrt(tr) * 2;
+        x = (m[9] - m[6]) / s;
+        y = (m[2] - m[8]) / s;
+        z = (m[4] - m[1]) / s;
+        w = 0.25 * s;
+    } else if (m[0] > m[5] && m[0] > m[10]) {
+        s = sqrt(1 + m[0] - m[5] - m[10]) * 2;
+        x = 0.25 * s;
+        y = (m[4] + m[1]) / s;
+        z = (m[2] + m[8]) / s;
+        w = (m[9] - m[6]) / s;
+    } else if (m[5] > m[10]) {
+        s = sqrt(1 + m[5] - m[0] - m[10]) * 2;
+        x = (m[4] + m[1]) / s;
+        y = 0.25 * s;
+        z = (m[9] + m[6]) / s;
+        w = (m[2] - m[8]) / s;
+    } else {
+        s = sqrt(1 + m[10] - m[0] - m[5]) * 2;
+        x = (m[2] + m[8]) / s;
+        y = (m[9] + m[6]) / s;
+        z = 0.25 * s;
+        w = (m[4] - m[1]) / s;
+    }
+    x = -x;
+    y = -y;
+    const double xx = x * x, xy = x * y, xz = x * z, xw = x * w, yy = y * y, yz = y * z, yw = y * w, zz = z * z, zw = z * w;
+    m[0] = 1 - 2 * (yy + zz);
+    m[1] = 2 * (xy - zw);
+    m[2] = 2 * (xz + yw);
+    m[4] = 2 * (xy + zw);
+    m[5] = 1 - 2 * (xx + zz);
+    m[6] = 2 * (yz - xw);
+    m[8] = 2 * (xz - yw);
+    m[9] = 2 * (yz + xw);
+    m[10] = 1 - 2 * (xx + yy);
+    m[12] = t[0];
+    m[13] = t[1];
+    m[14] = -t[2];
+    m[15] = 1;
+}
+
+OCVAR_HD void square_to_glmatrix(const float* sq, const CameraRec& cam, double ratio, double* gl) {
+    const double* K = cam.cameraMatrix;
+    double img[8], mn[8];
+    for (int i = 0; i < 4; i++) {
+        img[2 * i] = sq[2 * i];
+        img[2 * i + 1] = sq[2 * i + 1];
+        mn[2 * i] = (img[2 * i] - K[2]) * (1. / K[0]);
+        mn[2 * i + 1] = (img[2 * i + 1] - K[5]) * (1. / K[4]);
+    }
+    double p[6] = {0, 0, 0, 0, 0, 0};
+    double h[9];
+    if (rect_homography(ratio, mn, h)) {
+        const double n1 = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]), n2 = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+        const double s1 = 1. / fmax(n1, DBL_EPSILON), s2 = 1. / fmax(n2, DBL_EPSILON), s3 = 2. / fmax(n1 + n2, DBL_EPSILON);
+        const double a0 = h[0] * s1, a1 = h[3] * s1, a2 = h[6] * s1, b0 = h[1] * s2, b1 = h[4] * s2, b2 = h[7] * s2;
+        double Rm[9] = {a0, b0, a1 * b2 - a2 * b1, a1, b1, a2 * b0 - a0 * b2, a2, b2, a0 * b1 - a1 * b0};
+        // Rodrigues round trip (orthonormalise), then matrix -> vector once more as OpenCV does
+        double rv[3];
+        rotation_to_rvec(Rm, rv);
+        rodrigues(rv, Rm, nullptr);
+        rotation_to_rvec(Rm, p);
+        p[3] = h[2] * s3;
+        p[4] = h[5] * s3;
+        p[5] = h[8] * s3;
+    }
+    // Levenberg-Marquardt as CvLevMarq(6, 8, 20 iterations | FLT_EPSILON relative step)
+    double prev[6], J[48], e[8], JtJ[36], Jte[6], N[36], dx[6];
+    int lambdaLg10 = -3;
+    double prevErr = DBL_MAX;
+    for (int iters = 0;;) {
+        reproject(ratio, p, K, img, e, J);
+        for (int i = 0; i < 6; i++) {
+            for (int j = 0; j < 6; j++) {
+                double s = 0;
+                for (int k = 0; k < 8; k++) s += J[k * 6 + i] * J[k * 6 + j];
+                JtJ[i * 6 + j] = s;
+            }
+            double s = 0;
+            for (int k = 0; k < 8; k++) s += J[k * 6 + i] * e[k];
+            Jte[i] = s;
+        }
+        for (int i = 0; i < 6; i++) prev[i] = p[i];
+        if (iters == 0) prevErr = norm_n(e, 8);
+        double errNorm;
+        for (bool first = true;; first = false) {
+            if (!first) {
+                reproject(ratio, p, K, img, e, nullptr);
+                errNorm = norm_n(e, 8);
+                if (!(errNorm > prevErr && ++lambdaLg10 <= 16)) break;
+            }
+            const double lambda = exp(lambdaLg10 * 2.302585092994046);
+            for (int k = 0; k < 36; k++) N[k] = JtJ[k];
+            for (int i = 0; i < 6; i++) N[i * 7] *= 1. + lambda;
+            if (!chol6(N, Jte, dx))
+                for (int i = 0; i < 6; i++) dx[i] = 0;
+            for (int i = 0; i < 6; i++) p[i] = prev[i] - dx[i];
+        }
+        lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+        double d[6];
+        for (int i = 0; i < 6; i++) d[i] = p[i] - prev[i];
+        if (++iters >= 20 || norm_n(d, 6) / norm_n(prev, 6) < FLT_EPSILON) break;
+        prevErr = errNorm;
+    }
+    double R[9];
+    rodrigues(p, R, nullptr);
+    gl_from_pose(R, p + 3, gl);
+}
+
+}  // namespace ocvar

@@ -1,0 +1,324 @@
+// trace_core.h -- border following, polygon approximation and the quad filter of the square finder.
+//
+// Replaces, for one border, what the reference obtains from OpenCV inside cvarFindSquares
+// (/root/reference/src/opencvar.cpp:183-214): cvFindContours(RETR_LIST, CHAIN_APPROX_SIMPLE),
+// cvContourPerimeter, cvApproxPoly(DP, 2 % perimeter), cvContourArea, cvCheckContourConvexity and
+// the first-vertex border rule.
+//
+// MI355X formulation (not a translation of the sequential scan):
+//  * the binarise kernel stores, per pixel, the 8-bit mask of non-zero neighbours, so one step of the
+//    follower is one byte load + a rotate + a count-trailing-zeros;
+//  * cvFindContours discovers each border at the raster-first scan position among the positions where
+//    that border passes the west side (0->1 transition) or the east side (1->0 transition) of one of
+//    its pixels.  The follower therefore starts from every locally plausible start in parallel and
+//    drops out as soon as it meets a position of its own border that precedes its start; exactly one
+//    start per border survives, and the surviving starts sorted by position reproduce OpenCV's
+//    sequence order.  No labels are written into the image, so borders are independent work items.
+#pragma once
+#include "hd.h"
+#include <math.h>
+
+namespace ocvar {
+
+OCVAR_HD float sqrt_rn(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fsqrt_rn(v);
+#else
+    return sqrtf(v);
+#endif
+}
+
+// first set bit of the 8-bit mask m (m != 0) at direction from, from+1, ... (counter-clockwise)
+OCVAR_HD int first_ccw(unsigned m, int from) {
+    from &= 7;
+    unsigned r = ((m >> from) | (m << (8 - from))) & 0xFFu;
+    return (from + __builtin_ctz(r)) & 7;
+}
+// first set bit at direction from, from-1, ... (clockwise)
+OCVAR_HD int first_cw(unsigned m, int from) {
+    from &= 7;
+    unsigned r = ((m << (7 - from)) | (m >> (from + 1))) & 0xFFu;  // direction `from` -> bit 7
+    return (from - (__builtin_clz(r) - 24)) & 7;
+}
+
+enum TraceStatus { TRACE_OK = 0, TRACE_NOT_FIRST = 1, TRACE_SINGLE = 2, TRACE_OVERRUN = 3 };
+
+struct TraceStats {
+    int status;
+    int npts;
+    int minx, maxx, miny, maxy;
+    double perimeter;  // cvArcLength(closed): float32 segment lengths summed in double
+};
+
+// Follows the border that cvFindContours would start at scan position cpos (is_hole: 1->0 transition,
+// the border's first pixel is cpos-1).  nbr: neighbour masks of an sw-wide plane.  With STORE the
+// CHAIN_APPROX_SIMPLE points are written to out (x,y pairs).  Returns TRACE_NOT_FIRST as soon as a
+// scan position of this border smaller than cpos is met.
+template <bool STORE>
+OCVAR_HD TraceStats trace_border(const uint8_t* nbr, int sw, int plane, int cpos, int is_hole, int* out, int max_pts,
+                                 int max_steps) {
+    TraceStats st;
+    st.status = TRACE_OK;
+    st.npts = 0;
+    st.minx = st.miny = 0x7fffffff;
+    st.maxx = st.maxy = -0x7fffffff;
+    st.perimeter = 0.0;
+    const int i0 = cpos - is_hole;
+    int x = i0 % sw, y = i0 / sw;
+    unsigned m = nbr[i0];
+    if (m == 0) {  // single-pixel domain (only reachable for outer borders)
+        st.status = TRACE_SINGLE;
+        st.npts = 1;
+        st.minx = st.maxx = x;
+        st.miny = st.maxy = y;
+        if (STORE && max_pts > 0) {
+            out[0] = x;
+            out[1] = y;
+        }
+        return st;
+    }
+    int s = first_cw(m, (is_hole ? 0 : 4) - 1);
+    const int i1 = i0 + dir_dy(s) * sw + dir_dx(s);
+    int i3 = i0;
+    int prev_s = s ^ 4;
+    int fx = 0, fy = 0, lx = 0, ly = 0;
+    for (int step = 0;; step++) {
+        if (step >= max_steps) {
+            st.status = TRACE_OVERRUN;
+            return st;
+        }
+        const int s_end = s;
+        s = first_ccw(m, s_end + 1);
+        const int examined = (s - (s_end + 1)) & 7;  // zero neighbours passed on the way
+        // scan positions of this border at this pixel: west side passed -> i3, east side passed -> i3+1
+        if ((((4 - (s_end + 1)) & 7) < examined && i3 < cpos) || (((0 - (s_end + 1)) & 7) < examined && i3 + 1 < cpos)) {
+            st.status = TRACE_NOT_FIRST;
+            return st;
+        }
+        if (s != prev_s) {
+            if (st.npts == 0) {
+                fx = x;
+                fy = y;
+            } else {
+                float dx = (float)x - (float)lx, dy = (float)y - (float)ly;
+                st.perimeter += (double)sqrt_rn(dx * dx + dy * dy);
+            }
+            lx = x;
+            ly = y;
+            st.minx = x < st.minx ? x : st.minx;
+            st.maxx = x > st.maxx ? x : st.maxx;
+            st.miny = y < st.miny ? y : st.miny;
+            st.maxy = y > st.maxy ? y : st.maxy;
+            if (STORE && st.npts < max_pts) {
+                out[2 * st.npts] = x;
+                out[2 * st.npts + 1] = y;
+            }
+            st.npts++;
+            prev_s = s;
+        }
+        const int i4 = i3 + dir_dy(s) * sw + dir_dx(s);
+        x += dir_dx(s);
+        y += dir_dy(s);
+        if (i4 == i0 && i3 == i1) break;
+        i3 = i4;
+        if ((unsigned)i3 >= (unsigned)plane) {  // cannot happen on a consistent neighbour plane; never read outside it
+            st.status = TRACE_OVERRUN;
+            return st;
+        }
+        m = nbr[i3];
+        if (m == 0) {
+            st.status = TRACE_OVERRUN;
+            return st;
+        }
+        s = (s + 4) & 7;
+    }
+    if (st.npts > 1) {
+        float dx = (float)fx - (float)lx, dy = (float)fy - (float)ly;
+        st.perimeter += (double)sqrt_rn(dx * dx + dy * dy);
+    }
+    return st;
+}
+
+// Walks the border backwards (against the follower) from the start for at most max_back pixels and
+// reports whether a scan position of this border that precedes cpos lies there.  The follower runs
+// outer borders down their left side first, so a plausible-but-late outer start on an upper-left
+// staircase finds its predecessor one or two pixels behind it instead of a whole lap ahead.
+// (pixel, exit direction) -> (previous pixel, its exit direction) is the inverse of the follower's step:
+// the arrival direction is the first non-zero neighbour clockwise from exit-1.
+OCVAR_HD bool earlier_start_behind(const uint8_t* nbr, int sw, int plane, int cpos, int is_hole, int max_back) {
+    const int i0 = cpos - is_hole;
+    unsigned m = nbr[i0];
+    if (m == 0) return false;
+    const int b0 = first_cw(m, (is_hole ? 0 : 4) - 1);
+    int q = i0 + dir_dy(b0) * sw + dir_dx(b0);
+    int s = (b0 + 4) & 7;  // exit direction at q (towards the pixel we came from)
+    for (int k = 0; k < max_back; k++) {
+        if ((unsigned)q >= (unsigned)plane) return false;
+        m = nbr[q];
+        if (m == 0) return false;
+        const int b = first_cw(m, s - 1);
+        if (q == i0 && b == b0) return false;  // back at the start visit: whole lap, nothing earlier
+        const int examined = (s - (b + 1)) & 7;
+        if ((((4 - (b + 1)) & 7) < examined && q < cpos) || (((0 - (b + 1)) & 7) < examined && q + 1 < cpos)) return true;
+        q += dir_dy(b) * sw + dir_dx(b);
+        s = (b + 4) & 7;
+    }
+    return false;
+}
+
+struct DpSlice { int start, end; };
+
+// cvApproxPoly(CV_POLY_APPROX_DP) on a closed integer contour of count >= 1 points (x,y pairs in src).
+// dst must hold DP_MAX_OUT+1 points, stack count+2 slices.  Returns the vertex count after the
+// collinear clean-up, or DP_MAX_OUT+1 as soon as the result is known to exceed 4 vertices (the
+// clean-up removes at most every second vertex, so more than 8 raw vertices can never become 4).
+constexpr int DP_MAX_OUT = 8;
+
+OCVAR_HD int approx_poly_dp(const int* src, int count, double parameter, int* dst, DpSlice* stack) {
+    float eps = (float)parameter;  // cvApproxPoly passes the accuracy as float
+    eps *= eps;
+    int top = 0, new_count = 0;
+    DpSlice slice = {0, 0}, right = {0, 0};
+    int sx = 0, sy = 0;
+    bool le_eps = false;
+    int pos = 0;
+    // two approximately farthest points
+    for (int it = 0; it < 3; it++) {
+        int max_dist = 0;
+        pos = (pos + right.start) % count;
+        sx = src[2 * pos];
+        sy = src[2 * pos + 1];
+        int q = pos;
+        for (int j = 1; j < count; j++) {
+            if (++q >= count) q = 0;
+            int dx = src[2 * q] - sx, dy = src[2 * q + 1] - sy;
+            int dist = dx * dx + dy * dy;
+            if (dist > max_dist) {
+                max_dist = dist;
+                right.start = j;
+            }
+        }
+        le_eps = (float)max_dist <= eps;
+    }
+    if (le_eps) {
+        dst[0] = sx;
+        dst[1] = sy;
+        new_count = 1;
+    } else {
+        slice.start = pos;
+        slice.end = right.start += slice.start;
+        right.start -= right.start >= count ? count : 0;
+        right.end = slice.start;
+        if (right.end < right.start) right.end += count;
+        stack[top++] = right;
+        stack[top++] = slice;
+    }
+    while (top > 0) {
+        slice = stack[--top];
+        int e = slice.end >= count ? slice.end - count : slice.end;
+        int b = slice.start >= count ? slice.start - count : slice.start;
+        const int ex = src[2 * e], ey = src[2 * e + 1];
+        sx = src[2 * b];
+        sy = src[2 * b + 1];
+        if (slice.end > slice.start + 1) {
+            const int dx = ex - sx, dy = ey - sy;
+            int max_dist = 0;
+            int q = b;
+            for (int i = slice.start + 1; i < slice.end; i++) {
+                if (++q >= count) q = 0;
+                int d = (src[2 * q + 1] - sy) * dx - (src[2 * q] - sx) * dy;
+                d = d < 0 ? -d : d;
+                if (d > max_dist) {
+                    max_dist = d;
+                    right.start = i;
+                }
+            }
+            le_eps = (double)max_dist * max_dist <= (double)eps * ((double)dx * dx + (double)dy * dy);
+        } else {
+            le_eps = true;
+        }
+        if (le_eps) {
+            if (new_count >= DP_MAX_OUT) return DP_MAX_OUT + 1;
+            dst[2 * new_count] = sx;
+            dst[2 * new_count + 1] = sy;
+            new_count++;
+        } else {
+            right.end = slice.end;
+            slice.end = right.start;
+            stack[top++] = right;
+            stack[top++] = slice;
+        }
+    }
+    // clean-up of nearly collinear vertices on the closed ring
+    const int n = new_count;
+    int r = n - 1;
+    sx = dst[2 * r];
+    sy = dst[2 * r + 1];
+    if (++r >= n) r = 0;
+    int wpos = r;
+    int px = dst[2 * r], py = dst[2 * r + 1];
+    if (++r >= n) r = 0;
+    for (int i = 0; i < n && new_count > 2; i++) {
+        const int ex = dst[2 * r], ey = dst[2 * r + 1];
+        if (++r >= n) r = 0;
+        const int dx = ex - sx, dy = ey - sy;
+        int dist = (px - sx) * dy - (py - sy) * dx;
+        dist = dist < 0 ? -dist : dist;
+        if ((double)dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0) {
+            new_count--;
+            dst[2 * wpos] = sx = ex;
+            dst[2 * wpos + 1] = sy = ey;
+            if (++wpos >= n) wpos = 0;
+            px = dst[2 * r];
+            py = dst[2 * r + 1];
+            if (++r >= n) r = 0;
+            i++;
+            continue;
+        }
+        dst[2 * wpos] = sx = px;
+        dst[2 * wpos + 1] = sy = py;
+        if (++wpos >= n) wpos = 0;
+        px = ex;
+        py = ey;
+    }
+    return new_count;
+}
+
+// opencvar.cpp:199-206 on a 4-vertex result: |area| > 500, convex, first vertex inside the 2-px inset.
+OCVAR_HD bool quad_filter(const int* q, int img_w, int img_h) {
+    double a00 = 0;
+    double xi_1 = q[6], yi_1 = q[7];
+    for (int i = 0; i < 4; i++) {
+        double xi = q[2 * i], yi = q[2 * i + 1];
+        a00 += xi_1 * yi - xi * yi_1;
+        xi_1 = xi;
+        yi_1 = yi;
+    }
+    double area = a00 * 0.5;
+    if (!((area < 0 ? -area : area) > 500)) return false;
+    int orientation = 0;
+    int cx = q[0], cy = q[1];
+    int dx0 = cx - q[6], dy0 = cy - q[7];
+    for (int i = 0; i < 4; i++) {
+        int nx = q[2 * ((i + 1) & 3)], ny = q[2 * ((i + 1) & 3) + 1];
+        int dx = nx - cx, dy = ny - cy;
+        int dxdy0 = dx * dy0, dydx0 = dy * dx0;
+        orientation |= (dydx0 > dxdy0) ? 1 : ((dydx0 < dxdy0) ? 2 : 3);
+        if (orientation == 3) return false;
+        dx0 = dx;
+        dy0 = dy;
+        cx = nx;
+        cy = ny;
+    }
+    return q[0] > 2 && q[0] < img_w - 2 && q[1] > 2 && q[1] < img_h - 2;
+}
+
+// Cheap exact rejections before any point is stored: a 4-vertex result needs >= 4 contour points, and
+// a quad inscribed in the contour's bounding box cannot have more area than the box.
+OCVAR_HD bool worth_approximating(const TraceStats& st) {
+    if (st.status != TRACE_OK || st.npts < 4) return false;
+    long long bw = st.maxx - st.minx, bh = st.maxy - st.miny;
+    return bw * bh > 500;
+}
+
+}  // namespace ocvar

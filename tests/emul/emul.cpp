@@ -1,0 +1,197 @@
+// emul.cpp -- host build of the device algorithm cores (opencv-ar_amd/csrc/*_core.h) for CPU-side
+// logic tests.  TEST ONLY: nothing in the product links this; it exists so the formulation the HIP
+// kernels use (parallel border starts, neighbour-mask follower, ...) can be checked against the oracle
+// in the GPU-less container.
+#include "trace_core.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+using namespace ocvar;
+static int g_back = 32;
+static long long g_back_drops = 0;
+extern "C" void emul_set_back(int b) { g_back = b; }
+extern "C" long long emul_back_drops() { return g_back_drops; }
+
+extern "C" void emul_nbr_plane(const uint8_t* bin, int w, int h, uint8_t* nbr) {
+    auto b = [&](int x, int y) -> int {
+        if (x < 1 || y < 1 || x > w - 2 || y > h - 2) return 0;
+        return bin[(size_t)y * w + x] != 0;
+    };
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            unsigned m = 0;
+            for (int s = 0; s < 8; s++) m |= (unsigned)b(x + dir_dx(s), y + dir_dy(s)) << s;
+            nbr[(size_t)y * w + x] = (uint8_t)m;
+        }
+}
+
+// candidate rule of the binarise kernel + follower; output in cvFindContours list order
+extern "C" int emul_find_contours(const uint8_t* bin, int w, int h, int* pts, int max_pts, int* offs, int* starts,
+                                  int* holes, int max_contours, long long* work_steps) {
+    std::vector<uint8_t> nbr((size_t)w * h);
+    emul_nbr_plane(bin, w, h, nbr.data());
+    auto b = [&](int x, int y) -> int {
+        if (x < 1 || y < 1 || x > w - 2 || y > h - 2) return 0;
+        return bin[(size_t)y * w + x] != 0;
+    };
+    struct C { int pos, hole; std::vector<int> p; };
+    std::vector<C> found;
+    std::vector<int> buf(2 * (size_t)w * h * 4 + 16);
+    for (int y = 1; y < h - 1; y++)
+        for (int x = 1; x < w - 1; x++) {
+            int c = b(x, y);
+            bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1);
+            bool hole = !c && b(x - 1, y) && b(x, y - 1);
+            if (!outer && !hole) continue;
+            if (outer && g_back > 0 && earlier_start_behind(nbr.data(), w, w * h, y * w + x, 0, g_back)) { g_back_drops++; continue; }
+            TraceStats st = trace_border<true>(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, buf.data(), (int)buf.size() / 2, 4 * w * h + 16);
+            if (st.status == TRACE_OVERRUN) return -2;
+            if (st.status == TRACE_NOT_FIRST) continue;
+            C cc;
+            cc.pos = y * w + x;
+            cc.hole = hole;
+            cc.p.assign(buf.begin(), buf.begin() + 2 * st.npts);
+            found.push_back(std::move(cc));
+        }
+    std::sort(found.begin(), found.end(), [](const C& a, const C& b) { return a.pos > b.pos; });
+    if ((int)found.size() > max_contours) return -1;
+    int np = 0;
+    for (size_t i = 0; i < found.size(); i++) {
+        offs[i] = np;
+        starts[i] = found[i].pos;
+        holes[i] = found[i].hole;
+        int n = (int)found[i].p.size() / 2;
+        if (np + n > max_pts) return -1;
+        memcpy(pts + 2 * np, found[i].p.data(), sizeof(int) * 2 * n);
+        np += n;
+    }
+    offs[found.size()] = np;
+    return (int)found.size();
+}
+
+extern "C" int emul_approx_poly(const int* src, int n, double eps, int* dst) {
+    std::vector<DpSlice> stack(n + 2);
+    int tmp[2 * (DP_MAX_OUT + 1)];
+    int m = approx_poly_dp(src, n, eps, tmp, stack.data());
+    int k = m > DP_MAX_OUT ? DP_MAX_OUT : m;
+    memcpy(dst, tmp, sizeof(int) * 2 * k);
+    return m;
+}
+
+extern "C" int emul_quad_filter(const int* q, int w, int h) { return quad_filter(q, w, h) ? 1 : 0; }
+
+// trace statistics (perimeter, bbox) for one start
+extern "C" int emul_trace_stats(const uint8_t* nbr, int sw, int cpos, int is_hole, double* perimeter, int* bbox, int* npts) {
+    TraceStats st = trace_border<false>(nbr, sw, 1 << 30, cpos, is_hole, nullptr, 0, 1 << 30);
+    *perimeter = st.perimeter;
+    bbox[0] = st.minx; bbox[1] = st.maxx; bbox[2] = st.miny; bbox[3] = st.maxy;
+    *npts = st.npts;
+    return st.status;
+}
+
+// The K3 flow on one binary plane: candidates -> pass 1 (stats, first-check) -> prune -> pass 2 -> DP -> filter.
+// quads come out in the reference's push order (descending start).  stats: [0] candidates, [1] steps spent by
+// candidates that dropped out, [2] steps of surviving borders (pass 1), [3] borders, [4] borders approximated.
+extern "C" int emul_find_squares_bin(const uint8_t* bin, int sw, int sh, int img_w, int img_h, int* quads, int max_quads,
+                                     long long* stats) {
+    std::vector<uint8_t> nbr((size_t)sw * sh);
+    emul_nbr_plane(bin, sw, sh, nbr.data());
+    auto b = [&](int x, int y) -> int {
+        if (x < 1 || y < 1 || x > sw - 2 || y > sh - 2) return 0;
+        return bin[(size_t)y * sw + x] != 0;
+    };
+    struct Q { int start; int p[8]; };
+    std::vector<Q> out;
+    long long st_[5] = {0, 0, 0, 0, 0};
+    std::vector<int> buf;
+    for (int y = 1; y < sh - 1; y++)
+        for (int x = 1; x < sw - 1; x++) {
+            int c = b(x, y);
+            bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1);
+            bool hole = !c && b(x - 1, y) && b(x, y - 1);
+            if (!outer && !hole) continue;
+            if (outer && g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, 0, g_back)) { g_back_drops++; continue; }
+            st_[0]++;
+            // count steps by re-running with a step cap search (cheap instrumentation)
+            TraceStats st = trace_border<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, 4 * sw * sh + 16);
+            if (st.status == TRACE_NOT_FIRST) {
+                int lo = 0, hi = 4 * sw * sh + 16;  // smallest cap that still reports NOT_FIRST = steps taken
+                while (lo < hi) {
+                    int mid = (lo + hi) / 2;
+                    TraceStats t2 = trace_border<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, mid);
+                    if (t2.status == TRACE_NOT_FIRST) hi = mid; else lo = mid + 1;
+                }
+                st_[1] += lo + 1;
+                continue;
+            }
+            st_[3]++;
+            if (!worth_approximating(st)) continue;
+            st_[4]++;
+            buf.resize(2 * (size_t)st.npts);
+            trace_border<true>(nbr.data(), sw, sw * sh, y * sw + x, hole, buf.data(), st.npts, 4 * sw * sh + 16);
+            std::vector<DpSlice> stack(st.npts + 2);
+            int dst[2 * (DP_MAX_OUT + 1)];
+            int m = approx_poly_dp(buf.data(), st.npts, st.perimeter * 0.02, dst, stack.data());
+            if (m == 4 && quad_filter(dst, img_w, img_h)) {
+                Q q;
+                q.start = y * sw + x;
+                memcpy(q.p, dst, sizeof q.p);
+                out.push_back(q);
+            }
+        }
+    std::sort(out.begin(), out.end(), [](const Q& a, const Q& b) { return a.start > b.start; });
+    if ((int)out.size() > max_quads) return -1;
+    for (size_t i = 0; i < out.size(); i++) memcpy(quads + 8 * i, out[i].p, sizeof out[i].p);
+    if (stats) memcpy(stats, st_, sizeof st_);
+    return (int)out.size();
+}
+
+// instrumentation: per-candidate (type, steps until drop or -1 if survivor)
+extern "C" int emul_candidate_steps(const uint8_t* bin, int sw, int sh, int* type, int* steps, int maxn) {
+    std::vector<uint8_t> nbr((size_t)sw * sh);
+    emul_nbr_plane(bin, sw, sh, nbr.data());
+    auto b = [&](int x, int y) -> int {
+        if (x < 1 || y < 1 || x > sw - 2 || y > sh - 2) return 0;
+        return bin[(size_t)y * sw + x] != 0;
+    };
+    int n = 0;
+    for (int y = 1; y < sh - 1; y++)
+        for (int x = 1; x < sw - 1; x++) {
+            int c = b(x, y);
+            bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1);
+            bool hole = !c && b(x - 1, y) && b(x, y - 1);
+            if (!outer && !hole) continue;
+            if (outer && g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, 0, g_back)) { g_back_drops++; continue; }
+            TraceStats st = trace_border<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, 4 * sw * sh + 16);
+            int s = -1;
+            if (st.status == TRACE_NOT_FIRST) {
+                int lo = 0, hi = 4 * sw * sh + 16;
+                while (lo < hi) {
+                    int mid = (lo + hi) / 2;
+                    TraceStats t2 = trace_border<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, mid);
+                    if (t2.status == TRACE_NOT_FIRST) hi = mid; else lo = mid + 1;
+                }
+                s = lo + 1;
+            }
+            if (n < maxn) { type[n] = hole; steps[n] = s; }
+            n++;
+        }
+    return n;
+}
+
+#include "decode_core.h"
+#include "pose_core.h"
+#include "tail_core.h"
+
+extern "C" long long emul_read_code(const uint8_t* crop, int cw, int ch, int stride, const float* patPoint, int tw, int th) {
+    return read_code(crop, cw, ch, stride, patPoint, tw, th);
+}
+extern "C" void emul_square_to_glmatrix(const float* sq, const void* cam, double ratio, double* gl) {
+    square_to_glmatrix(sq, *(const CameraRec*)cam, ratio, gl);
+}
+extern "C" void emul_dedupe(int* markerId, const int* templateId, const double* score, int n) { dedupe(markerId, templateId, score, n); }
+extern "C" int emul_sizes(int* out) {
+    out[0] = sizeof(TemplateRec); out[1] = sizeof(CameraRec); out[2] = sizeof(MarkerRec); out[3] = sizeof(Roi);
+    return 4;
+}

@@ -1,0 +1,118 @@
+"""CPU tests of the device algorithm cores (opencv-ar_amd/csrc/*_core.h compiled for the host, tests/emul) against
+the oracle.  This checks the MI355X formulation itself -- parallel border starts instead of the sequential scan,
+neighbour-mask follower, early-out approximation, Cholesky/Newton pose -- without a GPU.  The host build is test-only."""
+import ctypes as C
+
+import numpy as np
+
+import helpers as H
+from helpers import P
+
+
+def emul_contours(em, b):
+    b = np.ascontiguousarray(b)
+    h, w = b.shape
+    maxp, maxc = 4 * b.size + 16, b.size + 16
+    pts = np.zeros(2 * maxp, np.int32)
+    offs = np.zeros(maxc + 1, np.int32)
+    starts = np.zeros(maxc, np.int32)
+    holes = np.zeros(maxc, np.int32)
+    n = em.emul_find_contours(P(b), w, h, P(pts), maxp, P(offs), P(starts), P(holes), maxc, None)
+    assert n >= 0
+    return [pts[2 * offs[i]:2 * offs[i + 1]].reshape(-1, 2).copy() for i in range(n)], starts[:n].copy(), holes[:n].copy()
+
+
+def same_contours(a, b):
+    (c1, s1, h1), (c2, s2, h2) = a, b
+    return len(c1) == len(c2) and (s1 == s2).all() and (h1 == h2).all() and all(
+        x.shape == y.shape and (x == y).all() for x, y in zip(c1, c2))
+
+
+def test_parallel_border_starts_equal_sequential_scan(emul):
+    rng = np.random.default_rng(1)
+    for trial in range(300):
+        h, w = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+        dens = rng.choice([0.1, 0.3, 0.5, 0.6, 0.7, 0.9])
+        b = (rng.random((h, w)) < dens).astype(np.uint8) * 255
+        if trial % 5 == 0:
+            b = np.kron((rng.random((h // 3 + 1, w // 3 + 1)) < dens).astype(np.uint8), np.ones((3, 3), np.uint8))[:h, :w] * 255
+        assert same_contours(H.oracle_contours(b), emul_contours(emul, b)), trial
+    b = (rng.random((240, 320)) < 0.55).astype(np.uint8) * 255
+    assert same_contours(H.oracle_contours(b), emul_contours(emul, b))
+
+
+def emul_squares(em, gray):
+    b = H.oracle_binarise(gray)
+    sh, sw = b.shape
+    h, w = gray.shape
+    q = np.zeros(8 * 4096, np.int32)
+    st = np.zeros(5, np.int64)
+    n = em.emul_find_squares_bin(P(b), sw, sh, w, h, P(q), 4096, P(st))
+    assert n >= 0
+    return q[:8 * n].reshape(n, 4, 2)
+
+
+def test_follow_approx_filter_on_synthetic_frames_and_crops(emul):
+    for cid, tex, names in [(2, 0, ["2x2-01"]), (3, 0, None), (3, 1, None)]:
+        cfg = H.synth_config(cid, textured=tex)
+        bgr, _ = H.synth_frame(cfg, 1, names)
+        gray = np.ascontiguousarray(bgr[..., 0])
+        q1 = H.oracle_find_squares(gray)
+        q2 = emul_squares(emul, gray)
+        assert q1.shape == q2.shape and (q1 == q2).all()
+        assert len(q1) >= 2 * len(names or H.TEMPLATE_ORDER)
+        for qd in q1[:12]:
+            x0, y0 = max(qd[:, 0].min() - 5, 0), max(qd[:, 1].min() - 5, 0)
+            x1, y1 = min(qd[:, 0].max() + 5, cfg.width), min(qd[:, 1].max() + 5, cfg.height)
+            crop = np.ascontiguousarray(gray[y0:y1, x0:x1])
+            a, b = H.oracle_find_squares(crop), emul_squares(emul, crop)
+            assert a.shape == b.shape and (a == b).all()
+
+
+def test_approx_poly_random_polygons(emul):
+    rng = np.random.default_rng(3)
+    o = H.oracle()
+    for _ in range(300):
+        n = int(rng.integers(1, 60))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        r = rng.uniform(20, 200) * (1 + 0.05 * rng.standard_normal(n))
+        pts = np.stack([300 + r * np.cos(ang), 300 + r * np.sin(ang)], 1).astype(np.int32)
+        pts = np.ascontiguousarray(pts)
+        eps = float(o.orc_arc_length_closed(P(pts), n) * 0.02)
+        d1 = np.zeros(2 * n + 4, np.int32)
+        d2 = np.zeros(32, np.int32)
+        m1 = o.orc_approx_poly(P(pts), n, eps, P(d1))
+        m2 = emul.emul_approx_poly(P(pts), n, eps, P(d2))
+        if m2 > 8:
+            assert m1 >= 5  # early-out: more than 8 raw vertices, only "more than 4 after clean-up" is promised
+        else:
+            assert m1 == m2 and (d1[:2 * m1] == d2[:2 * m1]).all()
+
+
+def test_decode_and_pose_cores(emul):
+    o = H.oracle()
+    nbits = 0
+    for cid, names in [(2, ["2x2-01"]), (3, None)]:
+        cfg = H.synth_config(cid)
+        tp = H.oracle_templates(names)
+        cam = H.oracle_camera(cfg.width, cfg.height)
+        bgr, _ = H.synth_frame(cfg, 2, names)
+        markers, cands, grey = H.oracle_registration(bgr, tp, cam)
+        gray = np.ascontiguousarray(grey[..., 0])
+        quads = H.oracle_find_squares(gray)
+        for c in cands:
+            qd = quads[c.markerId]
+            x0, y0 = max(qd[:, 0].min() - 5, 0), max(qd[:, 1].min() - 5, 0)
+            x1, y1 = min(qd[:, 0].max() + 5, cfg.width), min(qd[:, 1].max() + 5, cfg.height)
+            crop = gray[y0:y1, x0:x1]
+            t = tp[c.templateId]
+            pp = np.array(c.patPoint, np.float32)
+            bit = emul.emul_read_code(C.c_void_p(crop.ctypes.data), int(x1 - x0), int(y1 - y0), cfg.width, P(pp), t.width, t.height)
+            assert bit == c.bit
+            nbits += 1
+            sq = np.array(c.square, np.float32)
+            g1, g2 = np.zeros(16), np.zeros(16)
+            o.orc_square_to_matrix(P(sq), C.byref(cam), 1.0, P(g1))
+            emul.emul_square_to_glmatrix(P(sq), C.byref(cam), 1.0, P(g2))
+            assert np.abs(g1 - g2).max() <= 1e-6 * max(1.0, np.abs(g1).max())
+    assert nbits > 40

@@ -1,0 +1,188 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle on identical seeded frames.
+
+Bars (BASELINE.json north_star): marker/template ids, code bits, binary image, quads: bit-exact; quad corners
+within 0.5 px (they are integer-valued here, so also exact); 4x4 GL pose within 1e-4 relative."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+POSE_RTOL = 1e-4   # north_star: glMatrix within 1e-4 relative
+CORNER_TOL = 0.5   # north_star: quad corners within 0.5 px
+
+
+@pytest.fixture(scope="module")
+def oa():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a device"
+    import opencv_ar_amd
+    return opencv_ar_amd
+
+
+def make_detector(oa, cfg, names, batch):
+    tpls = H.oracle_templates(names)
+    cam = H.oracle_camera(cfg.width, cfg.height)
+    det = oa.Detector(cfg.width, cfg.height, max_batch=batch)
+    det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls])
+    det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+    return det, tpls, cam
+
+
+def check_frame(det, f, frame_bgr, tpls, cam, markers, counts, prev=None):
+    ref_m, ref_c, grey = H.oracle_registration(frame_bgr, tpls, cam, prev=prev)
+    h, w = frame_bgr.shape[:2]
+    # grey plane and binary image (interior; the HIP path stores it with cvFindContours' zeroed frame)
+    assert np.array_equal(det.debug_gray(f, w, h), grey[..., 0])
+    b_ref = H.oracle_binarise(np.ascontiguousarray(grey[..., 0]))
+    b_gpu = det.debug_binary(f, w, h)
+    assert np.array_equal(b_gpu[1:-1, 1:-1], b_ref[1:-1, 1:-1])
+    if prev is None:
+        q_ref = H.oracle_find_squares(np.ascontiguousarray(grey[..., 0]))
+        q_gpu = det.debug_frame_quads(f)
+        assert q_ref.shape == q_gpu.shape and np.array_equal(q_ref, q_gpu)
+    cands = det.debug_candidates(f)
+    assert len(cands) == len(ref_c)
+    for a, b in zip(cands, ref_c):
+        assert (a.markerId, a.templateId, a.orient, a.bit) == (b.markerId, b.templateId, b.orient, b.bit)
+        assert np.array_equal(np.array(a.square), np.array(b.square))
+        assert np.array_equal(np.array(a.patPoint), np.array(b.patPoint))
+    assert counts[f] == len(ref_m)
+    for k, r in enumerate(ref_m):
+        m = markers[f, k]
+        assert m["templateId"] == r.templateId and m["markerId"] == r.markerId and m["score"] == r.score
+        assert np.abs(m["square"] - np.array(r.square)).max() <= CORNER_TOL
+        assert m["aspectRatio"] == r.aspectRatio
+        g = np.array(r.glMatrix)
+        assert np.abs(m["glMatrix"] - g).max() <= POSE_RTOL * max(1.0, np.abs(g).max())
+    return ref_m, len(ref_c)
+
+
+def test_config1_single_frame_host_entry(oa):
+    cfg = H.synth_config(1)
+    det, tpls, cam = make_detector(oa, cfg, ["2x2-01"], 1)
+    frame, _ = H.synth_frame(cfg, 0, ["2x2-01"])
+    frames = frame[None].copy()
+    markers, counts = det.detect_host(frames, grey_in_place=True)
+    ref_m, n_c = check_frame(det, 0, frame, tpls, cam, markers, counts)
+    assert len(ref_m) == 1 and n_c >= 1
+    # reference side effect: the caller's frame is greyed in place (opencvar.cpp:624-627)
+    _, _, grey = H.oracle_registration(frame, tpls, cam)
+    assert np.array_equal(frames[0], grey)
+
+
+def test_config2_batch_of_small_frames(oa):
+    import torch
+    cfg = H.synth_config(2)
+    n = 24
+    det, tpls, cam = make_detector(oa, cfg, ["2x2-01"], n)
+    frames = np.stack([H.synth_frame(cfg, f, ["2x2-01"])[0] for f in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    markers, counts = det.detect_device(d.data_ptr(), cfg.width, cfg.height, n)
+    total = 0
+    for f in range(n):
+        total += check_frame(det, f, frames[f], tpls, cam, markers, counts)[1]
+    assert total >= 3 * n  # most of the 4 planted markers per frame decode
+    assert np.array_equal(d.cpu().numpy(), frames)  # not greyed unless asked
+
+
+def test_config3_full_hd_three_templates(oa):
+    import torch
+    cfg = H.synth_config(3)
+    n = 4
+    det, tpls, cam = make_detector(oa, cfg, None, n)
+    frames = np.stack([H.synth_frame(cfg, f)[0] for f in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    markers, counts = det.detect_device(d.data_ptr(), cfg.width, cfg.height, n)
+    for f in range(n):
+        ref_m, n_c = check_frame(det, f, frames[f], tpls, cam, markers, counts)
+        assert n_c >= 36 and 1 <= len(ref_m) <= 3
+
+
+def test_textured_background_and_odd_size(oa):
+    cfg = H.synth_config(3, textured=1, width=1001, height=701, grid_x=2, grid_y=2)
+    det, tpls, cam = make_detector(oa, cfg, None, 2)
+    frames = np.stack([H.synth_frame(cfg, f)[0] for f in range(2)])
+    markers, counts = det.detect_host(frames.copy())
+    for f in range(2):
+        check_frame(det, f, frames[f], tpls, cam, markers, counts)
+
+
+def test_config5_4k_jitter_and_occlusion(oa):
+    cfg = H.synth_config(5)
+    det, tpls, cam = make_detector(oa, cfg, None, 1)
+    frame, truth = H.synth_frame(cfg, 0)
+    markers, counts = det.detect_host(frame[None].copy())
+    ref_m, n_c = check_frame(det, 0, frame, tpls, cam, markers, counts)
+    assert n_c >= 100
+
+
+def test_empty_and_noise_frames(oa):
+    rng = np.random.default_rng(0)
+    w, h = 320, 240
+    cfg = H.synth_config(2, width=w, height=h)
+    det, tpls, cam = make_detector(oa, cfg, ["2x2-01"], 3)
+    frames = np.zeros((3, h, w, 3), np.uint8)
+    frames[0] = 220                                        # nothing to find
+    frames[1] = rng.integers(0, 256, (h, w, 3), np.uint8)  # coloured noise: exercises BGR2GRAY + many tiny borders
+    frames[2] = np.repeat(rng.integers(0, 256, (h, w, 1), np.uint8), 3, axis=2)
+    markers, counts = det.detect_host(frames.copy())
+    for f in range(3):
+        check_frame(det, f, frames[f], tpls, cam, markers, counts)
+    assert counts[0] == 0
+
+
+def test_find_squares_entry_matches_oracle_on_crops(oa):
+    cfg = H.synth_config(3)
+    det, tpls, cam = make_detector(oa, cfg, None, 1)
+    frame, _ = H.synth_frame(cfg, 5)
+    gray = np.ascontiguousarray(frame[..., 0])
+    quads = H.oracle_find_squares(gray)
+    for qd in quads[:10]:
+        x0, y0 = max(qd[:, 0].min() - 5, 0), max(qd[:, 1].min() - 5, 0)
+        x1, y1 = min(qd[:, 0].max() + 5, cfg.width), min(qd[:, 1].max() + 5, cfg.height)
+        crop = np.ascontiguousarray(gray[y0:y1, x0:x1])
+        ref = H.oracle_find_squares(crop)
+        got, n = det.find_squares(crop)
+        assert n == len(ref) and np.array_equal(got, ref)
+
+
+def test_stateful_tracking_second_call(oa):
+    cfg = H.synth_config(2)
+    det, tpls, cam = make_detector(oa, cfg, ["2x2-01"], 2)
+    frames = np.stack([H.synth_frame(cfg, f, ["2x2-01"])[0] for f in (3, 4)])
+    markers, counts = det.detect_host(frames.copy())
+    prev = [[markers[f, k] for k in range(counts[f])] for f in range(2)]
+    m2, c2 = det.detect_host(frames.copy(), prev=prev)
+    for f in range(2):
+        ref1, _, _ = H.oracle_registration(frames[f], tpls, cam)
+        check_frame(det, f, frames[f], tpls, cam, m2, c2, prev=ref1)
+
+
+def test_round_trip_properties_full_size(oa):
+    """Size-independent properties at the headline size: determinism across batch positions, and every decoded
+    4x4 marker's quad lies on a planted marker (corner within 6 px of the truth)."""
+    import torch
+    cfg = H.synth_config(3)
+    n = 8
+    det, tpls, cam = make_detector(oa, cfg, None, n)
+    frame, truth = H.synth_frame(cfg, 11)
+    frames = np.stack([frame] * n)
+    d = torch.from_numpy(frames).cuda()
+    markers, counts = det.detect_device(d.data_ptr(), cfg.width, cfg.height, n)
+    assert (counts == counts[0]).all()
+    for f in range(1, n):
+        assert markers[f].tobytes() == markers[0].tobytes()
+    cands = det.debug_candidates(n - 1)
+    tcorners = np.concatenate([t["corner"] for t in truth])
+    hits = 0
+    for c in cands:
+        if c.orient and c.templateId == 2:
+            sq = np.array(c.square).reshape(4, 2)
+            dist = np.sqrt(((sq[:, None, :] - tcorners[None]) ** 2).sum(-1)).min(1)
+            assert dist.max() < 6.0
+            hits += 1
+    assert hits >= 3

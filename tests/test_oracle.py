@@ -1,0 +1,153 @@
+"""CPU tests: the oracle against the reference's known answers.
+
+Pinned parts: acmath subset vs tests/golden/acmath_golden.json (generated from the reference's own acmath.cpp,
+tools/make_acmath_golden.py) and, when oracle/_ref is present, vs that library directly; template codes and the
+acArray2DToBit doc example.  Everything at the OpenCV boundary is PARITY UNPINNED (no OpenCV,
+no reference tests): only internal consistency and the behavioural facts recorded in SURVEY.md are checked."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import P
+
+GOLD = os.path.join(H.ROOT, "tests", "golden")
+
+
+def test_struct_layouts():
+    assert C.sizeof(H.Camera) == 248 and C.sizeof(H.Template) == 48 and C.sizeof(H.Marker) == 184
+    assert H.Marker.templateId.offset == 128 and H.Marker.markerId.offset == 132 and H.Marker.score.offset == 136
+    assert H.Marker.square.offset == 144 and H.Marker.aspectRatio.offset == 176 and H.Template.code.offset == 16
+
+
+def test_acmath_golden():
+    o = H.oracle()
+    g = json.load(open(os.path.join(GOLD, "acmath_golden.json")))
+    for c in g["array2d_to_bit"]:
+        a = np.array(c["arr"], np.uint8)
+        bit = C.c_longlong(0)
+        o.orc_acArray2DToBit(P(a), c["w"], c["h"], C.byref(bit))
+        assert bit.value == c["bit"]
+        back = np.zeros(c["w"] * c["h"], np.uint8)
+        o.orc_acBitToArray2D(c["bit"], P(back), c["w"], c["h"])
+        assert back.tolist() == c["back"]
+    for c in g["bit_rotate"]:
+        b = C.c_longlong(c["bit"])
+        o.orc_acBitRotate(C.byref(b), c["rot"], c["n"], c["n"])
+        assert b.value == c["out"]
+    for c in g["quaternion"]:
+        m = np.array(c["m"])
+        q = np.zeros(4)
+        o.orc_acMatrixToQuaternion(P(m), P(q))
+        assert np.array_equal(q, np.array(c["q"]))
+        m2 = np.zeros(16)
+        o.orc_acQuaternionToMatrix(P(q), P(m2))
+        assert np.array_equal(m2, np.array(c["m2"]))
+    for c in g["calc_length"]:
+        p = c["p"]
+        assert o.orc_acCalcLength(p[0], p[1], p[2], p[3]) == c["len"]
+    for c in g["transpose"]:
+        m = np.array(c["m"])
+        o.orc_acMatrixTranspose(P(m))
+        assert np.array_equal(m, np.array(c["t"]))
+
+
+def test_doc_example_acmath_h():
+    # /root/reference/include/opencvar/acmath.h:186-195 -> 0x00183C7E814224
+    rows = ["00000000", "00011000", "00111100", "01111110", "10000001", "01000010", "00100100"]
+    a = np.array([[int(ch) for ch in r] for r in rows], np.uint8)
+    bit = C.c_longlong(0)
+    H.oracle().orc_acArray2DToBit(P(a), 8, 7, C.byref(bit))
+    assert bit.value == 0x00183C7E814224
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(H.ROOT, "oracle", "_ref", "libacmath_ref.so")), reason="oracle/_ref not built")
+def test_acmath_against_compiled_reference():
+    ref = C.CDLL(os.path.join(H.ROOT, "oracle", "_ref", "libacmath_ref.so"))
+    ref.acBitRotate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    o = H.oracle()
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        n = int(rng.integers(1, 9))
+        bit = int(rng.integers(0, 2 ** min(62, n * n)))
+        rot = int(rng.integers(0, 4))
+        a, b = C.c_longlong(bit), C.c_longlong(bit)
+        ref.acBitRotate(C.byref(a), rot, n, n)
+        o.orc_acBitRotate(C.byref(b), rot, n, n)
+        assert a.value == b.value
+    # cvarGlMatrix net effect: 3x3 = (S R S)^T, S = diag(1,1,-1)  
+    r = np.array([0.1, -0.2, 0.3]); t = np.array([1.0, 2.0, 3.0])
+    R = np.zeros(9); o.orc_rodrigues_vec2mat(P(r), P(R), None)
+    m = np.zeros(16); o.orc_gl_matrix(P(R), P(t), P(m))
+    expect = [0.935754803, 0.283164961, -0.210191706, 0, -0.302932713, 0.950580618, -0.068031316, 0,
+              0.180540077, 0.127334575, 0.975290309, 0, 1, 2, -3, 1]
+    assert np.allclose(m, expect, atol=2e-9)
+
+
+def test_template_codes_golden():
+    tp = H.template_pixels()
+    tpls = H.oracle_templates()
+    for t, name in zip(tpls, H.TEMPLATE_ORDER):
+        assert [int(c) for c in t.code] == tp[name][1], name
+        assert t.width == tp[name][0].shape[1] - 2
+
+
+def test_binarise_is_edge_detector():
+    # uniform regions (black or white) come out 255, only the dark side of an edge is 0
+    img = np.full((120, 160), 220, np.uint8)
+    img[30:90, 40:120] = 0
+    b = H.oracle_binarise(img)
+    assert b[5, 5] == 255 and b[60, 80] == 255
+    assert (b[60, 38:48] == 0).any() and (b[60, 38:48] == 0).sum() <= 5
+
+
+def test_find_contours_small_cases():
+    b = np.zeros((7, 7), np.uint8)
+    b[3, 3] = 255
+    c, s, h = H.oracle_contours(b)
+    assert len(c) == 1 and c[0].tolist() == [[3, 3]] and h[0] == 0
+    b = np.zeros((8, 9), np.uint8)
+    b[2:6, 2:7] = 255
+    b[3:5, 3:6] = 0  # ring: outer border + hole border, list order = last discovered first
+    c, s, h = H.oracle_contours(b)
+    assert len(c) == 2 and h.tolist() == [1, 0]
+    assert c[1].tolist() == [[2, 2], [2, 5], [6, 5], [6, 2]]
+    # empty and frame-only images
+    assert len(H.oracle_contours(np.zeros((5, 5), np.uint8))[0]) == 0
+    full = np.full((6, 6), 255, np.uint8)
+    c, s, h = H.oracle_contours(full)
+    assert len(c) == 1 and c[0].tolist() == [[1, 1], [1, 4], [4, 4], [4, 1]]
+
+
+def test_registration_behaviour_config3():
+    """Facts recorded in SURVEY.md: <= 1 output marker per template (|| dedupe, D2), 2x2 reads only 0x8/0x4
+    under the stride quirk, 3x3 matches only upright, 4x4 in all four rotations (B.6)."""
+    cfg = H.synth_config(3)
+    tp = H.oracle_templates()
+    cam = H.oracle_camera(cfg.width, cfg.height)
+    bgr, truth = H.synth_frame(cfg, 0)
+    markers, cands, grey = H.oracle_registration(bgr, tp, cam)
+    assert 1 <= len(markers) <= 3 and len({m.templateId for m in markers}) == len(markers)
+    assert (grey[..., 0] == grey[..., 1]).all() and (grey[..., 1] == grey[..., 2]).all()
+    assert len(cands) % 3 == 0 and len(cands) >= 30
+    orients4 = {c.orient for c in cands if c.templateId == 2 and c.orient}
+    assert len(orients4) >= 3
+    for m in markers:
+        g = np.array(m.glMatrix).reshape(4, 4)
+        assert abs(np.linalg.det(g[:3, :3]) - 1) < 1e-6 and g[3, 2] < 0 and g[3, 3] == 1
+
+
+def test_tracking_stage_keeps_previous_markers():
+    cfg = H.synth_config(2)
+    tp = H.oracle_templates(["2x2-01"])
+    cam = H.oracle_camera(cfg.width, cfg.height)
+    bgr, _ = H.synth_frame(cfg, 3, ["2x2-01"])
+    m1, _, _ = H.oracle_registration(bgr, tp, cam)
+    assert len(m1) == 1
+    m2, _, _ = H.oracle_registration(bgr, tp, cam, prev=m1)
+    # the previous marker is re-associated (twice: concentric quads, D9) and a new one may be added
+    assert len(m2) >= 1
+    assert np.allclose(np.array(m2[0].glMatrix), np.array(m1[0].glMatrix), atol=1e-5) or m2[0].templateId == m1[0].templateId

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/acmath_golden.json by calling the reference's own acmath.cpp, compiled in place
+into oracle/_ref/libacmath_ref.so (recipe: oracle/Makefile, target `ref`).  Run in the build container only;
+the JSON (inputs + outputs, data only) is what travels to the GPU box."""
+import ctypes as C, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ref = C.CDLL(os.path.join(ROOT, "oracle/_ref/libacmath_ref.so"))
+ref.acBitToArray2D.argtypes = [C.c_longlong, C.c_void_p, C.c_int, C.c_int]
+ref.acBitRotate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+
+class Pf(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double)]
+ref.acCalcLength.restype = C.c_double
+ref.acCalcLength.argtypes = [Pf, Pf]
+
+rng = np.random.default_rng(20131)
+out = {"array2d_to_bit": [], "bit_rotate": [], "quaternion": [], "calc_length": [], "transpose": []}
+# doc example acmath.h:186-195
+doc = [[0,0,0,0,0,0,0,0],[0,0,0,1,1,0,0,0],[0,0,1,1,1,1,0,0],[0,1,1,1,1,1,1,0],[1,0,0,0,0,0,0,1],[0,1,0,0,0,0,1,0],[0,0,1,0,0,1,0,0]]
+cases = [(np.array(doc, np.uint8), 8, 7)]
+for _ in range(40):
+    w = int(rng.integers(1, 9)); h = int(rng.integers(1, 9))
+    cases.append(((rng.random((h, w)) < 0.5).astype(np.uint8), w, h))
+for a, w, h in cases:
+    a = np.ascontiguousarray(a); bit = C.c_longlong(0)
+    ref.acArray2DToBit(C.c_void_p(a.ctypes.data), w, h, C.byref(bit))
+    back = np.zeros(w * h, np.uint8)
+    ref.acBitToArray2D(bit.value, C.c_void_p(back.ctypes.data), w, h)
+    out["array2d_to_bit"].append({"w": w, "h": h, "arr": a.flatten().tolist(), "bit": bit.value, "back": back.tolist()})
+for _ in range(40):
+    n = int(rng.integers(1, 9))
+    bit0 = int(rng.integers(0, 2 ** min(62, n * n)))
+    for rot in range(4):
+        b = C.c_longlong(bit0)
+        ref.acBitRotate(C.byref(b), rot, n, n)
+        out["bit_rotate"].append({"n": n, "bit": bit0, "rot": rot, "out": b.value})
+def rot_m(axis, ang):
+    c, s = np.cos(ang), np.sin(ang)
+    R = {0: [[1,0,0],[0,c,-s],[0,s,c]], 1: [[c,0,s],[0,1,0],[-s,0,c]], 2: [[c,-s,0],[s,c,0],[0,0,1]]}[axis]
+    return np.array(R)
+mats = [rot_m(a, np.pi) for a in range(3)] + [np.eye(3)]
+for _ in range(40):
+    R = rot_m(0, rng.uniform(-3.2, 3.2)) @ rot_m(1, rng.uniform(-3.2, 3.2)) @ rot_m(2, rng.uniform(-3.2, 3.2))
+    mats.append(R)
+for R in mats:
+    m = np.zeros(16); 
+    for i in range(3):
+        for j in range(3): m[i*4+j] = R[i, j]
+    q = np.zeros(4); ref.acMatrixToQuaternion(C.c_void_p(m.ctypes.data), C.c_void_p(q.ctypes.data))
+    m2 = np.zeros(16); ref.acQuaternionToMatrix(C.c_void_p(q.ctypes.data), C.c_void_p(m2.ctypes.data))
+    out["quaternion"].append({"m": m.tolist(), "q": q.tolist(), "m2": m2.tolist()})
+for _ in range(20):
+    p = rng.uniform(-2000, 2000, 4)
+    out["calc_length"].append({"p": p.tolist(), "len": ref.acCalcLength(Pf(p[0], p[1]), Pf(p[2], p[3]))})
+m = rng.uniform(-5, 5, 16); t = m.copy(); ref.acMatrixTranspose(C.c_void_p(t.ctypes.data))
+out["transpose"].append({"m": m.tolist(), "t": t.tolist()})
+with open(os.path.join(ROOT, "tests/golden/acmath_golden.json"), "w") as f:
+    json.dump(out, f)
+print({k: len(v) for k, v in out.items()})
