@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the AR-marker detection path (BASELINE.json metric) on N MI355X.
+
+A "step" is one pass of the whole hot path (7 kernels: binarise, follow, order/crops, binarise crops, follow
+crops, decode, dedupe+pose, and the copy-out of the CvarMarker arrays) over one batch of synthetic frames per GPU.
+Workload at every N: BASELINE.json configs[2] -- 1920x1080, 16 planted markers/frame, templates 2x2/3x3/4x4.
+Frames are resident in HBM before the timed region.  For N > 1 (one process per GPU, torchrun) frames are
+sharded by frame, there is no data-path collective; the per-rank CvarMarker arrays are gathered to rank 0 over
+RCCL once per step (inside the timed region).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(frames, tpls, cam, budget_s=12.0):
+    """The oracle (CPU restatement of the reference path, oracle/) timed on a bounded sample of the same frames,
+    single thread -- the reference is single-threaded.  Reported beside the GPU number, never part of it."""
+    import helpers as H
+    H.oracle()
+    n, t0 = 0, time.perf_counter()
+    while n < len(frames) and (n < 3 or time.perf_counter() - t0 < budget_s):
+        H.oracle_registration(frames[n], tpls, cam)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} of the benchmark's 1920x1080 frames, oracle (CPU restatement; reference not runnable "
+                      f"without OpenCV), 1 thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--unique", type=int, default=16, help="distinct synthetic frames per GPU (tiled to the batch)")
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config id (3 = headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import helpers as H
+    import opencv_ar_amd as oa
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = H.synth_config(args.config)
+    names = ["2x2-01"] if args.config in (1, 2) else None
+    W, Hh, B = cfg.width, cfg.height, args.batch
+    uniq = max(1, min(args.unique, B))
+    # frame index space is sharded by frame: rank r owns frames r, r+world, ...
+    base = np.stack([H.synth_frame(cfg, rank + world * i, names)[0] for i in range(uniq)])
+    frames = np.concatenate([base] * ((B + uniq - 1) // uniq))[:B]
+    tpls = H.oracle_templates(names)   # template codes / camera are setup-side data structures
+    cam = H.oracle_camera(W, Hh)
+    det = oa.Detector(W, Hh, max_batch=B, device=local_rank)
+    det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls])
+    det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+    d_frames = torch.from_numpy(frames).cuda()
+    stream = torch.cuda.Stream()
+    nbytes_m = B * oa.MAX_MARKERS * 184
+    d_res = torch.empty(nbytes_m + 4 * B, dtype=torch.uint8, device="cuda")
+    gathered = [torch.empty_like(d_res) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    stage_sum = np.zeros(8, np.float64)
+
+    def step(timed):
+        det.enqueue_device(d_frames.data_ptr(), W, Hh, B, stream=stream.cuda_stream)
+        if world > 1:
+            det.results_to_device(d_res.data_ptr(), d_res.data_ptr() + nbytes_m, stream.cuda_stream)
+        markers, counts = det.collect(8)
+        if world > 1:
+            with torch.cuda.stream(stream):
+                dist.gather(d_res, gathered, dst=0)
+            stream.synchronize()
+        if timed:
+            stage_sum[:] += det.stage_ms()
+        return markers, counts
+
+    for _ in range(args.warmup):
+        markers, counts = step(False)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        markers, counts = step(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        K = args.steps
+        fps = world * B * K / dt
+        stage_ms = stage_sum / K
+        cnt = det.counters()
+        crop_pixels = float(cnt[4]) / B if len(cnt) > 4 else 0.0
+        n_out = float(counts.sum()) / B
+        # algorithmic bytes per frame = 6*W*H + sum of crop areas + 184 per output marker
+        alg_frame = 6.0 * W * Hh + crop_pixels + 184.0 * n_out
+        # dominant kernel by measured time; its algorithmic bytes per launch ("kernels")
+        kernels = [
+            ("binarise_frames_kernel", 0, 5.0 * W * Hh * B),            # 3 B BGR read + 1 B grey + 1 B mask per pixel
+            ("follow_kernel<frames>", 1, 1.0 * W * Hh * B),              # one read of the mask plane
+            ("binarise_crops_kernel", 3, 2.0 * crop_pixels * B),         # grey crop read + mask write
+            ("follow_kernel<crops>", 4, 1.0 * crop_pixels * B),
+        ]
+        dom = max(kernels, key=lambda k: stage_ms[k[1]])
+        ach = dom[2] / (stage_ms[dom[1]] * 1e-3) / 1e9
+        out = {
+            "metric": "frames/sec at 1920x1080, 16 markers/frame; 1/2/4/8 MI355X", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / K, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"configs[2]: {W}x{Hh}, {cfg.grid_x * cfg.grid_y} markers/frame, templates "
+                                   f"{'2x2' if names else '2x2/3x3/4x4 x 4 rotations'}, batch {B} frames/GPU/step "
+                                   f"({uniq} distinct), stateless", "frames_per_step_per_gpu": B,
+                       "parallelism": f"frame-sharded x{world}" + (", RCCL gather of CvarMarker arrays" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None},
+            "pipeline_roofline": {"bound": "hbm", "achieved": round(alg_frame * fps / world / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(alg_frame * fps / world / 1e9 / HBM_PEAK_GBS, 5),
+                                  "alg_bytes_per_frame": round(alg_frame)},
+            "binarise_roofline": {"achieved": round(5.0 * W * Hh * B / (stage_ms[0] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(5.0 * W * Hh * B / (stage_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stage_ms": {k: round(float(v), 4) for k, v in zip(
+                ["binarise_frames", "follow_frames", "order_crops", "binarise_crops", "follow_crops", "decode",
+                 "dedupe_pose", "batch_total"], stage_ms)},
+            "markers_per_frame": round(n_out, 3),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames, tpls, cam)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,11 @@ int ocvar_hip_enqueue(OcvarHip* ctx, uint8_t* d_bgr, int width, int height, int 
                       int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts, void* stream);
 int ocvar_hip_collect(OcvarHip* ctx, OcvarMarker* markers, int* counts, int max_per_frame);
 
+/* After ocvar_hip_enqueue: stream-ordered device-to-device copy of the batch's results into caller-owned device
+ * buffers, d_markers [n_frames][OCVAR_MAX_MARKERS] and d_counts [n_frames] -- for callers that gather results
+ * across GPUs (RCCL) before any host copy.  Does not wait; ocvar_hip_collect must still be called. */
+int ocvar_hip_results_to_device(OcvarHip* ctx, OcvarMarker* d_markers, int* d_counts, void* stream);
+
 /* Same, frames in host memory (copied over PCIe first; greyed frames are copied back when requested). */
 int ocvar_hip_detect_host(OcvarHip* ctx, uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,
                           int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts,

@@ -24,7 +24,7 @@ HIP_SYMBOLS = [
     "ocvar_hip_create", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
     "ocvar_hip_detect_device", "ocvar_hip_enqueue", "ocvar_hip_collect", "ocvar_hip_detect_host", "ocvar_hip_find_squares",
     "ocvar_hip_debug_gray", "ocvar_hip_debug_binary", "ocvar_hip_debug_frame_quads", "ocvar_hip_debug_candidates",
-    "ocvar_hip_stage_ms", "ocvar_hip_counters",
+    "ocvar_hip_stage_ms", "ocvar_hip_counters", "ocvar_hip_results_to_device",
 ]
 
 
@@ -66,6 +66,12 @@ def hip_lib():
         if not os.path.exists(HIP_LIB):
             raise OcvarError(f"{HIP_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(there is no CPU fallback for the detection path)")
+        try:
+            # torch ships its own HIP runtime; load it first so this library binds to the same one instead of
+            # bringing a second runtime into the process (two runtimes cannot both own the device)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(HIP_LIB)
         vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
         lib.ocvar_hip_create.argtypes = [C.POINTER(vp), i, i, i, i]
@@ -86,6 +92,7 @@ def hip_lib():
         lib.ocvar_hip_debug_candidates.argtypes = [vp, i, vp, i, vp]
         lib.ocvar_hip_stage_ms.argtypes = [vp, vp, i]
         lib.ocvar_hip_counters.argtypes = [vp, vp, i]
+        lib.ocvar_hip_results_to_device.argtypes = [vp, vp, vp, vp]
         _hip = lib
     return _hip
 
@@ -161,6 +168,11 @@ class Detector:
         counts = np.zeros(n, np.int32)
         self._check(self._lib.ocvar_hip_collect(self._ctx, _ptr(markers), _ptr(counts), max_per_frame), "collect")
         return markers, counts
+
+    def results_to_device(self, d_markers_ptr, d_counts_ptr, stream=None):
+        """Copies the enqueued batch's [n][MAX_MARKERS] marker records and [n] counts into caller-owned device
+        buffers (stream-ordered), e.g. torch tensors handed to an RCCL gather."""
+        self._check(self._lib.ocvar_hip_results_to_device(self._ctx, d_markers_ptr, d_counts_ptr, stream), "results_to_device")
 
     def detect_device(self, d_ptr, width, height, n_frames, **kw):
         max_per_frame = kw.pop("max_per_frame", MAX_MARKERS)

@@ -232,6 +232,19 @@ extern "C" int ocvar_hip_enqueue(OcvarHip* c, uint8_t* d_bgr, int width, int hei
                         stream ? (hipStream_t)stream : c->stream, 3);
 }
 
+extern "C" int ocvar_hip_results_to_device(OcvarHip* c, OcvarMarker* d_markers, int* d_counts, void* stream) {
+    if (!c || !d_markers || !d_counts || !c->pending) return OCVAR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->last_stream;
+    if (s != c->last_stream) {  // order behind the batch
+        HIP_TRY(c, hipStreamWaitEvent(s, c->ev[8], 0));
+    }
+    const int n = c->ws.n_frames;
+    HIP_TRY(c, hipMemcpyAsync(d_markers, c->ws.markers, (size_t)n * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_counts, c->ws.n_markers, n * sizeof(int), hipMemcpyDeviceToDevice, s));
+    return OCVAR_OK;
+}
+
 extern "C" int ocvar_hip_collect(OcvarHip* c, OcvarMarker* markers, int* counts, int max_per_frame) {
     if (!c || !counts || max_per_frame < 0 || (max_per_frame > 0 && !markers)) return OCVAR_E_ARG;
     int rc = wait_impl(c);
