@@ -1,0 +1,431 @@
+// opencvar_host.cpp -- host C++ mirror of the reference's public API (include/opencvar/opencvar.h), same
+// names, argument meaning and error behaviour as /root/reference/src/opencvar.cpp, on top of the C ABI of
+// include/ocvar_hip.h.  cvarArMultRegistration (reference 619-807) and cvarFindSquares (156-223) run on the
+// MI355X; everything else here is setup-side or tiny per-quad host arithmetic.
+//
+// Deliberate differences: no exception ever crosses the C boundary (failures return
+// 0 / an empty result and print one line to stderr); the reference's leaks (D12) are not reproduced; the camera
+// YAML reader and anti-aliased drawing are not provided (out of scope).
+#include "opencvar/opencvar.h"
+#include "opencvar/acmath.h"
+#include "ocvar_hip.h"
+#include "../csrc/decode_core.h"
+#include "../csrc/pose_core.h"
+#include "../csrc/tail_core.h"
+
+#include <zlib.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+
+static_assert(sizeof(CvarCamera) == sizeof(OcvarCamera) && sizeof(CvarCamera) == 248, "CvarCamera layout");
+static_assert(sizeof(CvarTemplate) == sizeof(OcvarTemplate) && sizeof(CvarTemplate) == 48, "CvarTemplate layout");
+static_assert(sizeof(CvarMarker) == sizeof(OcvarMarker) && sizeof(CvarMarker) == 184, "CvarMarker layout");
+
+// The sequence cvarFindSquares hands out.  With real OpenCV headers CvSeq is OpenCV's own type and these
+// debug-side functions would need cvCreateSeq; in this build (stand-in headers) the type is ours.
+struct CvSeq {
+    int total;  // number of CvPoint elements (4 per square), as the reference's callers read it
+    std::vector<CvPoint> elems;
+};
+
+namespace {
+
+std::mutex g_mu;
+OcvarHip* g_ctx = nullptr;
+int g_w = 0, g_h = 0;
+std::deque<std::unique_ptr<CvSeq>> g_seqs;  // keeps returned sequences alive (the reference uses CvMemStorage)
+
+OcvarHip* context_for(int w, int h) {
+    if (g_ctx && w <= g_w && h <= g_h) return g_ctx;
+    if (g_ctx) ocvar_hip_destroy(g_ctx);
+    g_ctx = nullptr;
+    const int dev = std::getenv("OCVAR_DEVICE") ? std::atoi(std::getenv("OCVAR_DEVICE")) : 0;
+    int rc = ocvar_hip_create(&g_ctx, dev, w < 64 ? 64 : w, h < 64 ? 64 : h, 1);
+    if (rc != OCVAR_OK) {
+        std::fprintf(stderr, "opencvar: no MI355X context (%d): %s\n", rc, g_ctx ? ocvar_hip_last_error(g_ctx) : "no gfx950 device");
+        if (g_ctx) ocvar_hip_destroy(g_ctx);
+        g_ctx = nullptr;
+        return nullptr;
+    }
+    g_w = w < 64 ? 64 : w;
+    g_h = h < 64 ? 64 : h;
+    return g_ctx;
+}
+
+// ---- minimal PNG reader (8-bit grey / grey+alpha / RGB / RGBA / palette, non-interlaced) over zlib ----
+uint32_t be32(const unsigned char* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+
+bool read_png_gray(const char* path, std::vector<unsigned char>& gray, int& w, int& h) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::vector<unsigned char> file;
+    unsigned char buf[4096];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);
+    std::fclose(f);
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (file.size() < 33 || std::memcmp(file.data(), sig, 8) != 0) return false;
+    size_t pos = 8;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<unsigned char> idat, plte;
+    w = h = 0;
+    while (pos + 12 <= file.size()) {
+        const uint32_t len = be32(&file[pos]);
+        const char* type = (const char*)&file[pos + 4];
+        if (pos + 12 + len > file.size()) return false;
+        const unsigned char* data = &file[pos + 8];
+        if (!std::memcmp(type, "IHDR", 4) && len >= 13) {
+            w = (int)be32(data);
+            h = (int)be32(data + 4);
+            depth = data[8];
+            ctype = data[9];
+            interlace = data[12];
+        } else if (!std::memcmp(type, "PLTE", 4)) {
+            plte.assign(data, data + len);
+        } else if (!std::memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!std::memcmp(type, "IEND", 4)) {
+            break;
+        }
+        pos += 12 + len;
+    }
+    if (w <= 0 || h <= 0 || w > 16384 || h > 16384 || depth != 8 || interlace != 0) return false;
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch) return false;
+    const size_t stride = (size_t)w * ch;
+    std::vector<unsigned char> raw((stride + 1) * h);
+    uLongf out_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) return false;
+    std::vector<unsigned char> img(stride * h);
+    for (int y = 0; y < h; y++) {
+        const unsigned char* in = &raw[(stride + 1) * y];
+        const int ft = in[0];
+        unsigned char* cur = &img[stride * y];
+        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= (size_t)ch ? cur[i - ch] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)ch) ? up[i - ch] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = b;
+            else if (ft == 3) pred = (a + b) >> 1;
+            else if (ft == 4) {
+                const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            } else if (ft != 0) return false;
+            cur[i] = (unsigned char)(in[1 + i] + pred);
+        }
+    }
+    gray.resize((size_t)w * h);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        const unsigned char* p = &img[i * ch];
+        int r, g, b;
+        if (ctype == 0 || ctype == 4) r = g = b = p[0];
+        else if (ctype == 3) {
+            if ((size_t)p[0] * 3 + 2 >= plte.size()) return false;
+            r = plte[p[0] * 3]; g = plte[p[0] * 3 + 1]; b = plte[p[0] * 3 + 2];
+        } else { r = p[0]; g = p[1]; b = p[2]; }
+        // cvLoadImage(GRAYSCALE) of a colour PNG: same fixed-point luma as BGR2GRAY
+        gray[i] = (unsigned char)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14);
+    }
+    return true;
+}
+
+bool image_ok(const IplImage* img) {
+    return img && img->imageData && img->depth == IPL_DEPTH_8U && img->nChannels == 3 && img->width >= 16 && img->height >= 16 &&
+           img->widthStep >= 3 * img->width;
+}
+
+}  // namespace
+
+extern "C" {
+
+void cvarCameraProjection(CvarCamera* c, double* p, int glstyle) {
+    const double nearplane = 0.1, farplane = 5000.0;  // opencvar.cpp:111-112
+    std::memset(p, 0, sizeof(double) * 16);
+    p[0] = 2. * c->cameraMatrix[0] / c->width;
+    p[5] = 2. * c->cameraMatrix[4] / c->height;
+    p[2] = 2. * (c->cameraMatrix[2] / c->width) - 1.;
+    p[6] = 2. * (c->cameraMatrix[5] / c->height) - 1.;
+    p[10] = -(farplane + nearplane) / (farplane - nearplane);
+    p[11] = -2. * farplane * nearplane / (farplane - nearplane);
+    p[14] = -1;
+    if (glstyle) acMatrixTranspose(p);
+}
+
+int cvarReadCamera(const char* filename, CvarCamera* c) {
+    if (filename) {
+        // reference: OpenCV FileStorage YAML (opencvar.cpp:53-71).  Not provided: behaves like a
+        // file that cannot be opened.
+        std::fprintf(stderr, "opencvar: camera file '%s' not read (YAML reader not provided); returning 0\n", filename);
+        return 0;
+    }
+    c->width = 640;
+    c->height = 480;
+    const double K[9] = {500, 0, c->width / 2.0, 0, 500, c->height / 2.0, 0, 0, 1};
+    std::memcpy(c->cameraMatrix, K, sizeof K);
+    std::memset(c->distCoeffs, 0, sizeof c->distCoeffs);
+    cvarCameraProjection(c, c->glProjection, 0);
+    acMatrixTranspose(c->glProjection);
+    return 1;
+}
+
+void cvarCameraScale(CvarCamera* c, int width, int height) {
+    const double ru = (double)width / c->width, rv = (double)height / c->height;
+    c->cameraMatrix[0] *= ru;
+    c->cameraMatrix[4] *= rv;
+    c->cameraMatrix[2] *= ru;
+    c->cameraMatrix[5] *= rv;
+    c->width = width;
+    c->height = height;
+    cvarCameraProjection(c, c->glProjection, 0);
+    acMatrixTranspose(c->glProjection);
+}
+
+void cvarGlMatrix(double* modelview, CvMat* rotate3, CvMat* translate) {
+    ocvar::gl_from_pose(rotate3->data.db, translate->data.db, modelview);
+}
+
+void cvarSquareInit(CvMat* mat, double ratio) {
+    const double v[12] = {-ratio, -1, 0, ratio, -1, 0, ratio, 1, 0, -ratio, 1, 0};
+    std::memcpy(mat->data.db, v, sizeof v);
+}
+
+void cvarReverseSquare(CvPoint2D32f sq[4]) {
+    const CvPoint2D32f t = sq[1];
+    sq[1] = sq[3];
+    sq[3] = t;
+}
+
+void cvarSquareToMatrix(CvPoint2D32f* points, CvarCamera* cam, double* modelview, double ratio) {
+    ocvar::CameraRec c;
+    std::memcpy(&c, cam, sizeof c);
+    ocvar::square_to_glmatrix(&points[0].x, c, ratio, modelview);
+}
+
+void cvarFindCamera(CvarCamera* cam, CvMat* objPts, CvMat* imgPts, double* modelview) {
+    // The reference passes arbitrary object points; this library's solver is the marker rectangle
+    // (+-ratio, +-1, 0) that cvarSquareInit produces -- the only use in the reference (opencvar.cpp:529-536).
+    const double ratio = std::fabs(objPts->data.db[0]);
+    CvPoint2D32f p[4];
+    for (int i = 0; i < 4; i++) {
+        p[i].x = (float)imgPts->data.db[2 * i];
+        p[i].y = (float)imgPts->data.db[2 * i + 1];
+    }
+    cvarSquareToMatrix(p, cam, modelview, ratio);
+}
+
+void cvarLoadTag(CvarTemplate* tpl, long long int bit, int width, int height, double scale) {
+    tpl->width = width;
+    tpl->height = height;
+    tpl->scale = scale;
+    for (int i = 0; i < 4; i++) {
+        tpl->code[i] = bit;
+        acBitRotate(&tpl->code[i], i, width, height);
+    }
+}
+
+int cvarLoadTemplateTag(CvarTemplate* tpl, const char* filename, double scale) {
+    std::vector<unsigned char> g;
+    int w = 0, h = 0;
+    if (!filename || !read_png_gray(filename, g, w, h) || w < 3 || h < 3 || (w - 2) * (h - 2) > 64) return 0;
+    // opencvar.cpp:291-301: inner (w-2)x(h-2) -> 8UC1 image (widthStep = align4) -> >100 -> flip vertically ->
+    // acArray2DToBit reading with stride = width (the reference's stride quirk; padding bytes read as 0)
+    const int iw = w - 2, ih = h - 2, ws = (iw + 3) & ~3;
+    std::vector<unsigned char> buf((size_t)ws * ih + (size_t)iw * ih, 0);
+    for (int y = 0; y < ih; y++)
+        for (int x = 0; x < iw; x++) buf[(size_t)y * ws + x] = g[(size_t)(ih - 1 - y + 1) * w + x + 1] > 100 ? 1 : 0;
+    long long bit = 0;
+    acArray2DToBit(buf.data(), iw, ih, &bit);
+    cvarLoadTag(tpl, bit, iw, ih, scale);
+    return 1;
+}
+
+void cvarSquare(CvPoint2D32f* s, int width, int height, int ccw) {
+    const float W = (float)(width - 1), H = (float)(height - 1);
+    s[0].x = 0; s[0].y = 0;
+    s[2].x = W; s[2].y = H;
+    if (ccw) { s[1].x = 0; s[1].y = H; s[3].x = W; s[3].y = 0; }
+    else     { s[1].x = W; s[1].y = 0; s[3].x = 0; s[3].y = H; }
+}
+
+void cvarRotSquare(CvPoint2D32f* src, int rot) { ocvar::rot_square(&src[0].x, rot); }
+
+CvRect cvarSquare2Rect(CvPoint2D32f pt[4]) {
+    int x = 50000, y = 50000, x2 = -50000, y2 = -50000;
+    for (int i = 0; i < 4; i++) {
+        if (pt[i].x < x) x = (int)pt[i].x;
+        if (pt[i].x > x2) x2 = (int)pt[i].x;
+        if (pt[i].y < y) y = (int)pt[i].y;
+        if (pt[i].y > y2) y2 = (int)pt[i].y;
+    }
+    CvRect r = {x, y, x2 - x, y2 - y};
+    return r;
+}
+
+int cvarTrack(CvPoint2D32f pt1[4], CvPoint2D32f pt2[4]) { return ocvar::track_square(&pt1[0].x, &pt2[0].x); }
+
+CvSeq* cvarFindSquares(IplImage* img, CvMemStorage* /*storage*/) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::unique_ptr<CvSeq> seq(new CvSeq{0, {}});
+    if (image_ok(img)) {
+        OcvarHip* ctx = context_for(img->width, img->height);
+        if (ctx) {
+            // the reference runs on a 3-channel image whose channels are equal after the in-place grey; take B
+            std::vector<unsigned char> gray((size_t)img->width * img->height);
+            for (int y = 0; y < img->height; y++)
+                for (int x = 0; x < img->width; x++)
+                    gray[(size_t)y * img->width + x] = (unsigned char)img->imageData[(size_t)y * img->widthStep + 3 * x];
+            std::vector<int> quads(OCVAR_MAX_QUADS * 8);
+            int n = 0;
+            if (ocvar_hip_find_squares(ctx, gray.data(), img->width, img->height, img->width, quads.data(), OCVAR_MAX_QUADS, &n) == OCVAR_OK) {
+                if (n > OCVAR_MAX_QUADS) n = OCVAR_MAX_QUADS;
+                for (int i = 0; i < 4 * n; i++) seq->elems.push_back(CvPoint{quads[2 * i], quads[2 * i + 1]});
+                seq->total = 4 * n;
+            } else {
+                std::fprintf(stderr, "opencvar: cvarFindSquares failed: %s\n", ocvar_hip_last_error(ctx));
+            }
+        }
+    }
+    g_seqs.push_back(std::move(seq));
+    if (g_seqs.size() > 256) g_seqs.pop_front();
+    return g_seqs.back().get();
+}
+
+int cvarGetSquare(CvSeq* squares, CvPoint2D32f* points) {
+    int res = 0;
+    for (int i = 0; squares && i + 3 < squares->total; i += 4, res++)
+        for (int j = 0; j < 4; j++) {
+            points[j].x = (float)squares->elems[i + j].x;
+            points[j].y = (float)squares->elems[i + j].y;
+        }
+    return res;
+}
+
+int cvarGetAllSquares(CvSeq* squares, vector<CvPoint2D32f>* pts) {
+    int res = 0;
+    for (int i = 0; squares && i + 3 < squares->total; i += 4, res++)
+        for (int j = 0; j < 4; j++) pts->push_back(CvPoint2D32f{(float)squares->elems[i + j].x, (float)squares->elems[i + j].y});
+    return res;
+}
+
+int cvarCompareSquare(IplImage* img, CvPoint2D32f* points) {
+    CvSeq* sq = cvarFindSquares(img, nullptr);
+    int match = 0;
+    for (int i = 0; i + 3 < sq->total; i += 4)
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 4; k++) {
+                const double dx = points[j].x - sq->elems[i + k].x, dy = points[j].y - sq->elems[i + k].y;
+                if (std::sqrt(dx * dx + dy * dy) < 10) match++;
+            }
+    return match;
+}
+
+int cvarDrawSquares(IplImage* img, CvSeq* squares) {
+    // the reference draws anti-aliased green polylines; this draws 1-px aliased ones (display aid)
+    int res = 0;
+    if (!image_ok(img) || !squares) return 0;
+    for (int i = 0; i + 3 < squares->total; i += 4, res++)
+        for (int e = 0; e < 4; e++) {
+            CvPoint a = squares->elems[i + e], b = squares->elems[i + ((e + 1) & 3)];
+            const int steps = std::max(std::abs(b.x - a.x), std::abs(b.y - a.y));
+            for (int s = 0; s <= steps; s++) {
+                const int x = a.x + (steps ? (int)std::lround((double)(b.x - a.x) * s / steps) : 0);
+                const int y = a.y + (steps ? (int)std::lround((double)(b.y - a.y) * s / steps) : 0);
+                if (x < 0 || y < 0 || x >= img->width || y >= img->height) continue;
+                unsigned char* p = (unsigned char*)img->imageData + (size_t)y * img->widthStep + 3 * x;
+                p[0] = 0; p[1] = 255; p[2] = 0;
+            }
+        }
+    return res;
+}
+
+void cvarInvertPerspective(IplImage* input, IplImage* output, CvPoint2D32f* src, CvPoint2D32f* dst) {
+    // general src->dst quad mapping (reference 510-516); per channel, same fixed-point sampling as the device path
+    if (!input || !output || !input->imageData || !output->imageData || input->nChannels != output->nChannels) return;
+    double A[8][9];
+    for (int i = 0; i < 4; i++) {
+        const double sx = src[i].x, sy = src[i].y, dx = dst[i].x, dy = dst[i].y;
+        const double r0[9] = {sx, sy, 1, 0, 0, 0, -sx * dx, -sy * dx, dx}, r1[9] = {0, 0, 0, sx, sy, 1, -sx * dy, -sy * dy, dy};
+        std::memcpy(A[i], r0, sizeof r0);
+        std::memcpy(A[i + 4], r1, sizeof r1);
+    }
+    for (int c = 0; c < 8; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 8; r++)
+            if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
+        if (A[piv][c] == 0) return;
+        for (int k = 0; k < 9; k++) std::swap(A[c][k], A[piv][k]);
+        for (int r = c + 1; r < 8; r++) {
+            const double f = A[r][c] / A[c][c];
+            for (int k = c; k < 9; k++) A[r][k] -= f * A[c][k];
+        }
+    }
+    float m32[9];
+    for (int c = 7; c >= 0; c--) {
+        double s = A[c][8];
+        for (int k = c + 1; k < 8; k++) s -= A[c][k] * A[k][8];
+        A[c][8] = s / A[c][c];
+    }
+    for (int i = 0; i < 8; i++) m32[i] = (float)A[i][8];
+    m32[8] = 1.f;
+    double M[9];
+    ocvar::invert_map(m32, M);
+    const int cn = input->nChannels;
+    std::vector<unsigned char> plane((size_t)input->width * input->height);
+    for (int ch = 0; ch < cn; ch++) {
+        for (int y = 0; y < input->height; y++)
+            for (int x = 0; x < input->width; x++)
+                plane[(size_t)y * input->width + x] = (unsigned char)input->imageData[(size_t)y * input->widthStep + cn * x + ch];
+        for (int y = 0; y < output->height; y++)
+            for (int x = 0; x < output->width; x++)
+                output->imageData[(size_t)y * output->widthStep + cn * x + ch] =
+                    (char)ocvar::warp_sample(plane.data(), input->width, input->height, input->width, M, x, y);
+    }
+}
+
+int cvarArMultRegistration(IplImage* image, vector<CvarMarker>* markers, vector<CvarTemplate> templates, CvarCamera* camera) {
+    if (!markers) return 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!image_ok(image) || !camera || templates.empty() || templates.size() > OCVAR_MAX_TEMPLATES) {
+        std::fprintf(stderr, "opencvar: cvarArMultRegistration: unsupported arguments (need 8UC3 image >= 16x16, 1..%d templates)\n",
+                     OCVAR_MAX_TEMPLATES);
+        markers->clear();
+        return 0;
+    }
+    OcvarHip* ctx = context_for(image->width, image->height);
+    if (!ctx) {
+        markers->clear();
+        return 0;
+    }
+    if (ocvar_hip_set_templates(ctx, reinterpret_cast<const OcvarTemplate*>(templates.data()), (int)templates.size()) != OCVAR_OK ||
+        ocvar_hip_set_camera(ctx, reinterpret_cast<const OcvarCamera*>(camera)) != OCVAR_OK) {
+        std::fprintf(stderr, "opencvar: %s\n", ocvar_hip_last_error(ctx));
+        markers->clear();
+        return 0;
+    }
+    std::vector<OcvarMarker> prev(OCVAR_MAX_MARKERS);
+    int n_prev = (int)std::min<size_t>(markers->size(), OCVAR_MAX_MARKERS);
+    if (n_prev) std::memcpy(prev.data(), markers->data(), n_prev * sizeof(OcvarMarker));
+    std::vector<OcvarMarker> out(OCVAR_MAX_MARKERS);
+    int count = 0;
+    const int rc = ocvar_hip_detect_host(ctx, (uint8_t*)image->imageData, image->width, image->height, image->widthStep,
+                                         (size_t)image->widthStep * image->height, 1, 1, n_prev ? prev.data() : nullptr,
+                                         n_prev ? &n_prev : nullptr, out.data(), &count, OCVAR_MAX_MARKERS);
+    markers->clear();
+    if (rc != OCVAR_OK) {
+        std::fprintf(stderr, "opencvar: detection failed (%d): %s\n", rc, ocvar_hip_last_error(ctx));
+        return 0;
+    }
+    if (count > OCVAR_MAX_MARKERS) count = OCVAR_MAX_MARKERS;
+    markers->resize(count);
+    if (count) std::memcpy(markers->data(), out.data(), count * sizeof(OcvarMarker));
+    return (int)markers->size();
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+"""Host C++ mirror of the reference API (lib/libopencv-ar.so): symbol surface and setup-side functions on CPU,
+the full cvarArMultRegistration path through the ARTest-equivalent sample on GPU."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import P
+
+LIB = os.path.join(H.PKG, "lib", "libopencv-ar.so.1.0.0")
+
+
+@pytest.fixture(scope="module")
+def host():
+    import __graft_entry__ as g
+    g.build()
+    return C.CDLL(LIB)
+
+
+# /root/reference/include/opencvar/opencvar.h:84-262 (21 cvar*) and acmath.h:65-223 (30 ac*, acMatrixTranslate included)
+CVAR = ["cvarReadCamera", "cvarCameraScale", "cvarCameraProjection", "cvarGlMatrix", "cvarFindSquares", "cvarSquareInit",
+        "cvarReverseSquare", "cvarFindCamera", "cvarLoadTemplateTag", "cvarLoadTag", "cvarCompareSquare", "cvarDrawSquares",
+        "cvarGetSquare", "cvarSquare", "cvarRotSquare", "cvarInvertPerspective", "cvarSquareToMatrix", "cvarSquare2Rect",
+        "cvarGetAllSquares", "cvarTrack", "cvarArMultRegistration"]
+AC = ["acVectorPrint", "acVectorAdd", "acVectorDeduct", "acVectorCrossProduct", "acVectorNormal", "acVectorMagnitude",
+      "acVectorNormalise", "acVectorNormal2", "acRad2Deg", "acDeg2Rad", "acMatrixRotate", "acMatrixTranslate", "acMatrixScale",
+      "acMatrixIdentity", "acMatrixDotProduct", "acMatrixMultiply", "acMatrixPrint", "acMatrixTranspose", "acMatrixToQuaternion",
+      "acQuaternionToMatrix", "acAngle", "acCalcLength", "acMatrix4Invert", "acMatrix4GetDeterminant", "acMatrixDecompose",
+      "acArray2DRotateub", "acArray2DPrintub", "acArray2DToBit", "acBitToArray2D", "acBitRotate"]
+
+
+def test_exports_reference_symbols_unmangled(host):
+    for name in CVAR + AC:
+        assert hasattr(host, name), name
+    out = subprocess.check_output(["objdump", "-p", LIB]).decode()
+    assert "SONAME" in out and "libopencv-ar.so.1.0" in out  # CMakeLists.txt:28-39 of the reference
+
+
+def test_acmath_host_against_golden(host):
+    g = json.load(open(os.path.join(H.ROOT, "tests", "golden", "acmath_golden.json")))
+    host.acBitToArray2D.argtypes = [C.c_longlong, C.c_void_p, C.c_int, C.c_int]
+    host.acBitRotate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    for c in g["array2d_to_bit"]:
+        a = np.array(c["arr"], np.uint8)
+        bit = C.c_longlong(0)
+        host.acArray2DToBit(P(a), c["w"], c["h"], C.byref(bit))
+        assert bit.value == c["bit"]
+    for c in g["bit_rotate"]:
+        b = C.c_longlong(c["bit"])
+        host.acBitRotate(C.byref(b), c["rot"], c["n"], c["n"])
+        assert b.value == c["out"]
+    for c in g["quaternion"]:
+        m = np.array(c["m"]); q = np.zeros(4)
+        host.acMatrixToQuaternion(P(m), P(q))
+        assert np.array_equal(q, np.array(c["q"]))
+        m2 = np.zeros(16)
+        host.acQuaternionToMatrix(P(q), P(m2))
+        assert np.array_equal(m2, np.array(c["m2"]))
+
+
+def test_template_loader_and_camera(host):
+    host.cvarLoadTemplateTag.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    tp = H.template_pixels()
+    for name in H.TEMPLATE_ORDER:
+        t = H.Template()
+        path = os.path.join(H.ROOT, "assets", "templates", name + ".png").encode()
+        assert host.cvarLoadTemplateTag(C.byref(t), path, 0.01) == 1
+        assert [int(c) for c in t.code] == tp[name][1]
+    t = H.Template()
+    assert host.cvarLoadTemplateTag(C.byref(t), b"/nonexistent.png", 0.01) == 0
+    cam, ref = H.Camera(), H.oracle_camera(1920, 1080)
+    assert host.cvarReadCamera(None, C.byref(cam)) == 1
+    host.cvarCameraScale(C.byref(cam), 1920, 1080)
+    assert bytes(cam) == bytes(ref)
+    assert host.cvarReadCamera(b"camera.yml", C.byref(cam)) == 0
+
+
+@pytest.mark.gpu
+def test_artest_headless_matches_oracle():
+    exe = os.path.join(H.PKG, "bin", "artest_headless")
+    png = os.path.join(H.ROOT, "assets", "templates", "2x2-01.png")
+    out = subprocess.check_output([exe, png, "1", "0"], timeout=300).decode()
+    cfg = H.synth_config(1)
+    frame, _ = H.synth_frame(cfg, 0, ["2x2-01"])
+    tpls, cam = H.oracle_templates(["2x2-01"]), H.oracle_camera(cfg.width, cfg.height)
+    m1, _, _ = H.oracle_registration(frame, tpls, cam)
+    m2, _, _ = H.oracle_registration(frame, tpls, cam, prev=m1)
+    assert "template 2x2 codes 8 2 1 4" in out and "frame greyed in place: yes" in out
+    counts = [int(x) for x in re.findall(r"pass \d: (\d+) marker", out)]
+    assert counts == [len(m1), len(m2)]
+    gls = [np.array([float(v) for v in line.split()[1:]]) for line in out.splitlines() if line.strip().startswith("gl")]
+    for got, ref in zip(gls, m1 + m2):
+        r = np.array(ref.glMatrix)
+        assert np.abs(got - r).max() <= 1e-4 * max(1.0, np.abs(r).max()) + 1e-6
