@@ -53,6 +53,7 @@ def main():
     import torch
     import helpers as H
     import opencv_ar_amd as oa
+    from opencv_ar_amd import sharding as S
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -70,7 +71,7 @@ def main():
     W, Hh, B = cfg.width, cfg.height, args.batch
     uniq = max(1, min(args.unique, B))
     # frame index space is sharded by frame: rank r owns frames r, r+world, ...
-    base = np.stack([H.synth_frame(cfg, rank + world * i, names)[0] for i in range(uniq)])
+    base = np.stack([H.synth_frame(cfg, S.frame_of(rank, world, i), names)[0] for i in range(uniq)])
     frames = np.concatenate([base] * ((B + uniq - 1) // uniq))[:B]
     tpls = H.oracle_templates(names)   # template codes / camera are setup-side data structures
     cam = H.oracle_camera(W, Hh)
@@ -79,9 +80,8 @@ def main():
     det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
     d_frames = torch.from_numpy(frames).cuda()
     stream = torch.cuda.Stream()
-    nbytes_m = B * oa.MAX_MARKERS * 184
-    d_res = torch.empty(nbytes_m + 4 * B, dtype=torch.uint8, device="cuda")
-    gathered = [torch.empty_like(d_res) for _ in range(world)] if (world > 1 and rank == 0) else None
+    nbytes_m = B * S.MAX_MARKERS * S.MARKER_BYTES
+    d_res = torch.empty(S.block_bytes(B), dtype=torch.uint8, device="cuda")
 
     stage_sum = np.zeros(8, np.float64)
 
@@ -92,8 +92,10 @@ def main():
         markers, counts = det.collect(8)
         if world > 1:
             with torch.cuda.stream(stream):
-                dist.gather(d_res, gathered, dst=0)
+                blocks = S.gather_blocks(d_res, rank, world, dist)
             stream.synchronize()
+            if rank == 0 and not timed:
+                S.unpack(blocks, B, oa.MARKER_DTYPE)  # warm-up only: checks the gathered blocks decode
         if timed:
             stage_sum[:] += det.stage_ms()
         return markers, counts

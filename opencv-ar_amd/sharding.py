@@ -1,0 +1,41 @@
+"""Frame sharding and result gathering for N GPUs of one node (one process per GPU, torch.distributed).
+
+Frames are independent work units: rank r owns global frames r, r+N, r+2N, ...; the only exchange is
+one gather of the fixed-size result block per batch to rank 0 (backend "nccl" = RCCL over xGMI on the GPUs,
+"gloo" in the CPU tests).  Result block per rank: B x MAX_MARKERS CvarMarker records (184 B) then B int32 counts."""
+import numpy as np
+import torch
+
+MARKER_BYTES, MAX_MARKERS = 184, 64
+
+
+def frame_of(rank, world, local_index):
+    """global frame index processed at position local_index of rank's batch"""
+    return rank + world * local_index
+
+
+def block_bytes(batch):
+    return batch * MAX_MARKERS * MARKER_BYTES + 4 * batch
+
+
+def gather_blocks(local_block, rank, world, dist=None):
+    """local_block: uint8 tensor [block_bytes(B)] on the rank's device.  Returns on rank 0 a list of `world`
+    tensors (rank order), elsewhere None."""
+    if world == 1:
+        return [local_block]
+    out = [torch.empty_like(local_block) for _ in range(world)] if rank == 0 else None
+    dist.gather(local_block, out, dst=0)
+    return out
+
+
+def unpack(blocks, batch, marker_dtype):
+    """blocks (rank order) -> dict global_frame -> (count, markers[:min(count, MAX_MARKERS)]) on rank 0"""
+    world = len(blocks)
+    res = {}
+    for r, blk in enumerate(blocks):
+        raw = blk.cpu().numpy()
+        markers = raw[:batch * MAX_MARKERS * MARKER_BYTES].view(marker_dtype).reshape(batch, MAX_MARKERS)
+        counts = raw[batch * MAX_MARKERS * MARKER_BYTES:].view(np.int32)
+        for i in range(batch):
+            res[frame_of(r, world, i)] = (int(counts[i]), markers[i, :min(int(counts[i]), MAX_MARKERS)].copy())
+    return res
