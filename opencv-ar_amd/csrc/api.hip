@@ -82,10 +82,10 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     w.cap_crop_tiles = (int)std::min<size_t>(B * 4096, (size_t)1 << 30);
     w.cap_crop_quads = (int)(B * MAXQ * 4);
     w.cap_pool_ints = (long long)B * (1 << 20);
-    w.cap_crop_pixels = (long long)(2 * B * WH);
+    w.cap_crop_pixels = (long long)(2 * B * (size_t)(max_width + 4) * max_height);
     int rc;
     if ((rc = dev_alloc(c, &w.gray, B * WH))) return rc;
-    if ((rc = dev_alloc(c, &w.nbr_frame, B * WH))) return rc;
+    if ((rc = dev_alloc(c, &w.nbr_frame, B * (size_t)(max_width + 4) * max_height))) return rc;
     if ((rc = dev_alloc(c, &w.nbr_crop, (size_t)w.cap_crop_pixels))) return rc;
     if ((rc = dev_alloc(c, &w.cands_frame, (size_t)w.cap_frame_cands))) return rc;
     if ((rc = dev_alloc(c, &w.cands_crop, (size_t)w.cap_crop_cands))) return rc;
@@ -169,7 +169,17 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     w.H = height;
     w.sw = width & ~1;
     w.sh = height & ~1;
+    w.ns = (w.sw + 3) & ~3;
     w.n_frames = n_frames;
+    w.frame_strips = (w.sw + MARCH_STRIP - 1) / MARCH_STRIP;
+    {   // rows per binarise work unit: about 128, even, chunks of equal size
+        int chunks = (w.sh + 64) / 128;
+        if (chunks < 1) chunks = 1;
+        int rows = (w.sh + chunks - 1) / chunks;
+        rows = (rows + 1) & ~1;
+        w.frame_chunk_rows = rows;
+        w.frame_chunks = (w.sh + rows - 1) / rows;
+    }
     HIP_TRY(c, hipMemsetAsync(w.counters, 0, CNT_COUNT * sizeof(int), s));
     HIP_TRY(c, hipMemsetAsync(w.n_quads_frame, 0, n_frames * sizeof(int), s));
     if (prev && prev_counts) {
@@ -336,12 +346,12 @@ extern "C" int ocvar_hip_debug_gray(OcvarHip* c, int frame, uint8_t* h) {
 extern "C" int ocvar_hip_debug_binary(OcvarHip* c, int frame, uint8_t* h) {
     if (!c || !h || frame < 0 || frame >= c->ws.n_frames) return OCVAR_E_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    const int sw = c->ws.sw, sh = c->ws.sh;
-    std::vector<uint8_t> nbr((size_t)sw * sh);
-    HIP_TRY(c, hipMemcpy(nbr.data(), c->ws.nbr_frame + (size_t)frame * sw * sh, nbr.size(), hipMemcpyDeviceToHost));
+    const int sw = c->ws.sw, sh = c->ws.sh, ns = c->ws.ns;
+    std::vector<uint8_t> nbr((size_t)ns * sh);
+    HIP_TRY(c, hipMemcpy(nbr.data(), c->ws.nbr_frame + (size_t)frame * ns * sh, nbr.size(), hipMemcpyDeviceToHost));
     // pixel (x,y) is the west neighbour (bit 4) of (x+1,y); the 1-px frame is zero as cvFindContours makes it
     for (int y = 0; y < sh; y++)
-        for (int x = 0; x < sw; x++) h[(size_t)y * sw + x] = (x + 1 < sw && ((nbr[(size_t)y * sw + x + 1] >> 4) & 1)) ? 255 : 0;
+        for (int x = 0; x < sw; x++) h[(size_t)y * sw + x] = (x + 1 < sw && ((nbr[(size_t)y * ns + x + 1] >> 4) & 1)) ? 255 : 0;
     return OCVAR_OK;
 }
 

@@ -1,37 +1,24 @@
 // binarise.hip -- fused grey + pyramid denoise + adaptive threshold + neighbour-mask kernel (gfx950).
 //
-// One LDS-tiled pass replaces the image stages of cvarFindSquares
-// (/root/reference/src/opencvar.cpp:156-184): cvCloneImage, cvPyrDown(5x5), cvPyrUp, cvCvtColor(BGR2GRAY),
-// cvAdaptiveThreshold(GAUSSIAN_C, 7x7, delta 8) -- and, in frame mode, the BGR2GRAY of
-// cvarArMultRegistration (opencvar.cpp:624-627).  It also does the part of cvFindContours that is local
-// (opencvar.cpp:183-184): zeroing the 1-px frame, and spotting where a border can begin.
+// Replaces the image stages of cvarFindSquares (/root/reference/src/opencvar.cpp:156-184): cvCloneImage,
+// cvPyrDown(5x5), cvPyrUp, cvCvtColor(BGR2GRAY), cvAdaptiveThreshold(GAUSSIAN_C, 7x7, delta 8) -- in frame mode
+// also the BGR2GRAY of cvarArMultRegistration (opencvar.cpp:624-627) -- and the local part of cvFindContours
+// (opencvar.cpp:183-184): zeroing the 1-px frame and spotting where a border can begin.
 //
-// Per output tile of 64x32 pixels a workgroup stages, all in LDS:
-//   G  80x48 u8   grey source incl. the 8-px halo (BORDER_REFLECT_101 applied at load)
-//   Ph 48x38 u16  horizontal [1 4 6 4 1] at even columns      P 22x38 u8  pyrDown result ((v+128)>>8)
-//   U  40x72 u8   pyrUp result ((v+32)>>6), replicate-clamped to the image for the Gaussian
-//   H  40x66 u16  horizontal [8 28 56 72 56 28 8]              B 34x66 u8  threshold (src - mean > -8), frame zeroed
-// and writes the grey plane (frame mode), the 8-bit non-zero-neighbour mask per pixel, and the list of
-// plausible border starts.  HBM traffic per pixel: 3 B read + 1 B grey + 1 B mask (frame mode).
-// Integer arithmetic throughout, so the result is bit-identical to the sequential definition.
+// "Wave march": one 64-lane wavefront owns a strip of 256 columns (4 pixels per lane: 224 output columns + a
+// 16-column halo on each side) and walks down a chunk of rows.  Everything vertical lives in registers as
+// sliding windows (5 rows of the horizontal pyrDown sums, 3 rows of the horizontally up-sampled pyramid,
+// 7 rows of the horizontal Gaussian sums, 3 rows of threshold bits); everything horizontal is a 4-pixel packed
+// word handed to the neighbour lane.  No LDS allocation, no workgroup barrier, one coalesced dword load/store
+// per lane per row and plane.  HBM traffic per pixel: 3 B read + 1 B grey + 1 B mask (frame mode).
+// The arithmetic is the integer arithmetic of the definition, so the output is bit-identical:
+//   pyrDown  [1 4 6 4 1]^2, (v+128)>>8, BORDER_REFLECT_101        pyrUp  [1 6 1]/[4 4], (v+32)>>6, borders -1->1, n->n-1
+//   Gaussian [8 28 56 72 56 28 8]^2, (v+32768)>>16, BORDER_REPLICATE    threshold  src - mean > -8
 #include "kernels.h"
 
 namespace ocvar {
 
-constexpr int TW = TILE_W, TH = TILE_H, NT = 256;
-constexpr int GW = TW + 16, GH = TH + 16;
-constexpr int PW = TW / 2 + 6, PH = TH / 2 + 6;
-constexpr int UW = TW + 8, UH = TH + 8;
-constexpr int BW = TW + 2, BH = TH + 2;
-
-struct TileLds {
-    uint8_t G[GH][GW];
-    uint16_t Ph[GH][PW + 2];
-    uint8_t P[PH][PW + 2];
-    uint8_t U[UH][UW];
-    uint16_t Hh[UH][BW + 2];
-    uint8_t B[BH][BW + 2];
-};
+constexpr int SV = MARCH_STRIP;  // output columns per strip (lanes 4..59)
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -39,206 +26,339 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
-__device__ __forceinline__ int grey_of(const uint8_t* p) {
-    return (p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14;
+__device__ __forceinline__ unsigned grey_of(unsigned b, unsigned g, unsigned r) { return (b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14; }
+
+// lane i receives lane i-1 / lane i+1 (DPP whole-wave shifts: one VALU move, no LDS traffic)
+__device__ __forceinline__ unsigned up1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned down1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(unsigned v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ unsigned as_u32(us2 v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ unsigned dot4(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+__device__ __forceinline__ unsigned alignb(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+__device__ __forceinline__ unsigned byte_of(unsigned v, int j) { return (v >> (8 * j)) & 255u; }
+
+// BGR2GRAY with 8-bit coefficient halves: 1868 = 7*256+76, 9617 = 37*256+145, 4899 = 19*256+35
+__device__ __forceinline__ unsigned grey_px(unsigned w, unsigned khi, unsigned klo) { return (dot4(w, khi, 0) * 256u + dot4(w, klo, 8192u)) >> 14; }
+
+struct MarchOut {
+    uint8_t* gray;          // frame mode: grey plane of this frame (stride gray_stride), else null
+    long long gray_stride;
+    uint8_t* nbr;           // neighbour-mask plane of this ROI, stride ns
+    int ns;
+    int roi;
+    StartCand* cands;
+    int* n_cands;
+    int cap_cands;
+    int* err;
+};
+
+// Lookup of the 8-neighbour mask (+ start type) of the centre pixel of a 3x3 bit window:
+// index = row above (3 bits: x-1,x,x+1) | row << 3 | row below << 6.  Low byte: mask in follower direction
+// order E,NE,N,NW,W,SW,S,SE; bits 8..9: 1 = can start an outer border, 2 = can start a hole border.
+__device__ __forceinline__ void build_nbr_lut(unsigned short* lut) {
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) {
+        const unsigned a = i & 7, m = (i >> 3) & 7, b = i >> 6;
+        const unsigned nw = a & 1, n = (a >> 1) & 1, ne = (a >> 2) & 1, w = m & 1, c = (m >> 1) & 1, e = (m >> 2) & 1;
+        const unsigned sw_ = b & 1, s = (b >> 1) & 1, se = (b >> 2) & 1;
+        unsigned v = e | (ne << 1) | (n << 2) | (nw << 3) | (w << 4) | (sw_ << 5) | (s << 6) | (se << 7);
+        if (c && !(w | nw | n | ne)) v |= 1u << 8;   // can be the raster-first pixel of a component
+        else if (!c && w && n) v |= 2u << 8;         // can be the raster-first pixel of a hole
+        lut[i] = (unsigned short)v;
+    }
+    __syncthreads();
 }
 
-// index of the pyramid sample that stands in for virtual index v (pyrUp borders: -1 -> 1, n -> n-1)
-__device__ __forceinline__ int pyr_index(int v, int n) { return v < 0 ? (n > 1 ? 1 : 0) : (v >= n ? n - 1 : v); }
-
+// One work unit: strip `strip` of an (sw x sh) ROI, output rows [Y0, Y1).
 template <bool BGR>
-__device__ void binarise_tile(TileLds& L, const uint8_t* src, long long src_stride, int roi_index, int img_w, int img_h,
-                              int sw, int sh, int X0, int Y0, uint8_t* gray_out, long long gray_stride, uint8_t* bgr_out,
-                              uint8_t* nbr, StartCand* cands, int* n_cands, int cap_cands, int* err) {
-    const int tid = threadIdx.x;
-    const int pw = sw >> 1, ph = sh >> 1;
-    const int px0 = X0 / 2 - 3, py0 = Y0 / 2 - 3;
+__device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int sh, int strip, int Y0, int Y1, const MarchOut& o,
+                           const unsigned short* lut, unsigned* stage) {
+    const int lane = threadIdx.x & 63;
+    const int XS = strip * SV - 16;
+    const int c0 = XS + 4 * lane;
+    const int pw = sw >> 1, ph_ = sh >> 1;
+    const int k0 = c0 >> 1;  // pyramid column of the lane's first pyramid sample (c0 is a multiple of 4)
+    const bool out_lane = lane >= 4 && lane < 60 && c0 < sw;
+    const bool needed = c0 + 3 >= -16 && c0 < sw + 16;  // beyond every halo: never consumed
+    const bool fast = c0 >= 0 && c0 + 3 < sw;
+    const bool aligned = BGR ? ((src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) : true;
+    const bool left_edge = strip == 0;             // lanes 0..3 hold virtual columns -16..-1
+    const int L1 = (sw - 1 - XS) >> 2, j1 = (sw - 1 - XS) & 3;  // lane / byte of column sw-1
+    const bool right_edge = L1 <= 61;              // some needed lane holds columns >= sw
+    const bool gray_dword = o.gray && (o.gray_stride & 3) == 0 && c0 + 3 < sw;
+    // reflected source columns of the lanes that straddle an image edge (BORDER_REFLECT_101)
+    int xr0 = 0, xr1 = 0, xr2 = 0, xr3 = 0;
+    if (needed && !fast) {
+        xr0 = reflect101(c0, sw) * (BGR ? 3 : 1);
+        xr1 = reflect101(c0 + 1, sw) * (BGR ? 3 : 1);
+        xr2 = reflect101(c0 + 2, sw) * (BGR ? 3 : 1);
+        xr3 = reflect101(c0 + 3, sw) * (BGR ? 3 : 1);
+    }
+    unsigned colmask = 0;  // which of the lane's 4 columns lie inside cvFindContours' zeroed frame
+    for (int j = 0; j < 4; j++) colmask |= (c0 + j >= 1 && c0 + j <= sw - 2) ? (1u << j) : 0u;
 
-    // 1. grey tile with halo
-    for (int i = tid; i < GW * GH; i += NT) {
-        const int gx = i % GW, gy = i / GW;
-        const int x = reflect101(X0 - 8 + gx, sw), y = reflect101(Y0 - 8 + gy, sh);
-        const uint8_t* p = src + (long long)y * src_stride + (BGR ? 3 * x : x);
-        L.G[gy][gx] = BGR ? (uint8_t)grey_of(p) : *p;
-    }
-    __syncthreads();
-
-    if (BGR) {  // grey plane (and the reference's in-place grey of the caller's frame)
-        for (int i = tid; i < TW * TH; i += NT) {
-            const int tx = i % TW, ty = i / TW;
-            const int x = X0 + tx, y = Y0 + ty;
-            if (x < sw && y < sh) {
-                const uint8_t g = L.G[ty + 8][tx + 8];
-                gray_out[(long long)y * gray_stride + x] = g;
-                if (bgr_out) {
-                    uint8_t* q = bgr_out + (long long)y * src_stride + 3 * x;
-                    q[0] = q[1] = q[2] = g;
-                }
-            }
-        }
-        // odd width / height: the last column / row lies outside the even working size but still is greyed
-        if (img_w > sw && X0 + TW >= sw) {
-            for (int ty = tid; ty < TH + 1; ty += NT) {
-                const int y = Y0 + ty;
-                const bool last_row = (ty == TH);
-                if ((!last_row && y < sh) || (last_row && img_h > sh && Y0 + TH >= sh)) {
-                    const int yy = last_row ? sh : y;
-                    const uint8_t g = (uint8_t)grey_of(src + (long long)yy * src_stride + 3 * sw);
-                    gray_out[(long long)yy * gray_stride + sw] = g;
-                    if (bgr_out) {
-                        uint8_t* q = bgr_out + (long long)yy * src_stride + 3 * sw;
-                        q[0] = q[1] = q[2] = g;
-                    }
-                }
-            }
-        }
-        if (img_h > sh && Y0 + TH >= sh) {
-            for (int tx = tid; tx < TW; tx += NT) {
-                const int x = X0 + tx;
-                if (x < sw) {
-                    const uint8_t g = (uint8_t)grey_of(src + (long long)sh * src_stride + 3 * x);
-                    gray_out[(long long)sh * gray_stride + x] = g;
-                    if (bgr_out) {
-                        uint8_t* q = bgr_out + (long long)sh * src_stride + 3 * x;
-                        q[0] = q[1] = q[2] = g;
-                    }
-                }
-            }
-        }
-    }
-
-    // 2a. pyrDown, horizontal
-    for (int i = tid; i < GH * PW; i += NT) {
-        const int tx = i % PW, gy = i / PW;
-        int c0 = 2 * (pyr_index(px0 + tx, pw) - px0);
-        c0 = c0 < 0 ? 0 : (c0 > GW - 5 ? GW - 5 : c0);  // no-op for any image of 2 or more columns
-        const uint8_t* g = &L.G[gy][c0];
-        L.Ph[gy][tx] = (uint16_t)(g[0] + 4 * g[1] + 6 * g[2] + 4 * g[3] + g[4]);
-    }
-    __syncthreads();
-    // 2b. pyrDown, vertical
-    for (int i = tid; i < PH * PW; i += NT) {
-        const int tx = i % PW, ty = i / PW;
-        int r0 = 2 * (pyr_index(py0 + ty, ph) - py0);
-        r0 = r0 < 0 ? 0 : (r0 > GH - 5 ? GH - 5 : r0);
-        const int v = L.Ph[r0][tx] + 4 * L.Ph[r0 + 1][tx] + 6 * L.Ph[r0 + 2][tx] + 4 * L.Ph[r0 + 3][tx] + L.Ph[r0 + 4][tx];
-        L.P[ty][tx] = (uint8_t)((v + 128) >> 8);
-    }
-    __syncthreads();
-    // 3. pyrUp at replicate-clamped coordinates
-    for (int i = tid; i < UH * UW; i += NT) {
-        const int ux = i % UW, uy = i / UW;
-        int ex = X0 - 4 + ux, ey = Y0 - 4 + uy;
-        ex = ex < 0 ? 0 : (ex > sw - 1 ? sw - 1 : ex);
-        ey = ey < 0 ? 0 : (ey > sh - 1 ? sh - 1 : ey);
-        int kx = (ex >> 1) - px0, ky = (ey >> 1) - py0;
-        kx = kx < 1 ? 1 : (kx > PW - 2 ? PW - 2 : kx);  // no-ops, see the halo arithmetic in DESIGN.md
-        ky = ky < 1 ? 1 : (ky > PH - 2 ? PH - 2 : ky);
-        int r0, r1, r2 = 0;  // horizontally up-sampled values of rows ky-1, ky, ky+1 (as needed)
-        if (ex & 1) {
-            if (ey & 1) {
-                r0 = 4 * (L.P[ky][kx] + L.P[ky][kx + 1]);
-                r1 = 4 * (L.P[ky + 1][kx] + L.P[ky + 1][kx + 1]);
-                L.U[uy][ux] = (uint8_t)((4 * (r0 + r1) + 32) >> 6);
+    // Border starts are staged per wave in LDS and appended to the global list with ONE atomic per flush: a
+    // single list counter only sustains ~90 atomics/us chip-wide, which one atomic per image row would exceed.
+    int staged = 0;  // wave-uniform
+    auto flush = [&]() {
+        if (staged == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        int base = 0;
+        if (lane == 0) base = atomicAdd(o.n_cands, staged);
+        base = __shfl(base, 0);
+        for (int i = lane; i < staged; i += 64) {
+            const unsigned e = stage[i];
+            if (base + i < o.cap_cands) {
+                StartCand sc;
+                sc.roi = o.roi;
+                sc.pos = (int)(e & 0x7fffffffu);
+                sc.is_hole = (int)(e >> 31);
+                o.cands[base + i] = sc;
             } else {
-                r0 = 4 * (L.P[ky - 1][kx] + L.P[ky - 1][kx + 1]);
-                r1 = 4 * (L.P[ky][kx] + L.P[ky][kx + 1]);
-                r2 = 4 * (L.P[ky + 1][kx] + L.P[ky + 1][kx + 1]);
-                L.U[uy][ux] = (uint8_t)((r0 + 6 * r1 + r2 + 32) >> 6);
-            }
-        } else {
-            if (ey & 1) {
-                r0 = L.P[ky][kx - 1] + 6 * L.P[ky][kx] + L.P[ky][kx + 1];
-                r1 = L.P[ky + 1][kx - 1] + 6 * L.P[ky + 1][kx] + L.P[ky + 1][kx + 1];
-                L.U[uy][ux] = (uint8_t)((4 * (r0 + r1) + 32) >> 6);
-            } else {
-                r0 = L.P[ky - 1][kx - 1] + 6 * L.P[ky - 1][kx] + L.P[ky - 1][kx + 1];
-                r1 = L.P[ky][kx - 1] + 6 * L.P[ky][kx] + L.P[ky][kx + 1];
-                r2 = L.P[ky + 1][kx - 1] + 6 * L.P[ky + 1][kx] + L.P[ky + 1][kx + 1];
-                L.U[uy][ux] = (uint8_t)((r0 + 6 * r1 + r2 + 32) >> 6);
+                atomicOr(o.err, ERR_CAND_OVERFLOW);
             }
         }
-    }
-    __syncthreads();
-    // 4. Gaussian, horizontal
-    for (int i = tid; i < UH * BW; i += NT) {
-        const int bx = i % BW, uy = i / BW;
-        const uint8_t* u = &L.U[uy][bx];
-        L.Hh[uy][bx] = (uint16_t)(8 * (u[0] + u[6]) + 28 * (u[1] + u[5]) + 56 * (u[2] + u[4]) + 72 * u[3]);
-    }
-    __syncthreads();
-    // 5. Gaussian, vertical + threshold + zero frame
-    for (int i = tid; i < BH * BW; i += NT) {
-        const int bx = i % BW, by = i / BW;
-        const int x = X0 - 1 + bx, y = Y0 - 1 + by;
-        int b = 0;
-        if (x >= 1 && x <= sw - 2 && y >= 1 && y <= sh - 2) {
-            const int acc = 8 * (L.Hh[by][bx] + L.Hh[by + 6][bx]) + 28 * (L.Hh[by + 1][bx] + L.Hh[by + 5][bx]) +
-                            56 * (L.Hh[by + 2][bx] + L.Hh[by + 4][bx]) + 72 * L.Hh[by + 3][bx];
-            const int mean = (acc + 32768) >> 16;
-            b = ((int)L.U[by + 3][bx + 3] - mean > -8) ? 1 : 0;
-        }
-        L.B[by][bx] = (uint8_t)b;
-    }
-    __syncthreads();
-    // 6. neighbour masks + plausible border starts
-    const int lane = tid & 63;
-    for (int i = tid; i < TW * TH; i += NT) {
-        const int tx = i % TW, ty = i / TW;
-        const int x = X0 + tx, y = Y0 + ty;
-        const int bx = tx + 1, by = ty + 1;
-        int type = -1;
-        if (x < sw && y < sh) {
-            const int c = L.B[by][bx];
-            const int e = L.B[by][bx + 1], ne = L.B[by - 1][bx + 1], n = L.B[by - 1][bx], nw = L.B[by - 1][bx - 1];
-            const int w = L.B[by][bx - 1], swp = L.B[by + 1][bx - 1], s = L.B[by + 1][bx], se = L.B[by + 1][bx + 1];
-            nbr[(long long)y * sw + x] = (uint8_t)(e | (ne << 1) | (n << 2) | (nw << 3) | (w << 4) | (swp << 5) | (s << 6) | (se << 7));
-            if (c && !(w | nw | n | ne)) type = 0;        // can be the raster-first pixel of a component
-            else if (!c && w && n) type = 1;              // can be the raster-first pixel of a hole
-        }
-        const unsigned long long mask = __ballot(type >= 0);
-        if (mask) {
-            int base = 0;
-            const int leader = __ffsll((long long)mask) - 1;
-            if (lane == leader) base = atomicAdd(n_cands, __popcll(mask));
-            base = __shfl(base, leader);
-            if (type >= 0) {
-                const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-                if (slot < cap_cands) {
-                    StartCand sc;
-                    sc.roi = roi_index;
-                    sc.pos = y * sw + x;
-                    sc.is_hole = type;
-                    cands[slot] = sc;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        staged = 0;
+    };
+
+    // raw source words of virtual row v (3 dwords BGR / 1 dword grey for fast lanes, 4 pixels for edge lanes)
+    struct Raw { unsigned d0, d1, d2; };
+    auto fetch = [&](int v) -> Raw {
+        Raw r = {0u, 0u, 0u};
+        if (!needed) return r;
+        const uint8_t* row = src + (long long)reflect101(v, sh) * src_stride;
+        if (fast) {
+            if (BGR) {
+                if (aligned) {
+                    const unsigned* p = reinterpret_cast<const unsigned*>(row + 3 * c0);
+                    r.d0 = p[0]; r.d1 = p[1]; r.d2 = p[2];
                 } else {
-                    atomicOr(err, ERR_CAND_OVERFLOW);
+                    const uint8_t* p = row + 3 * c0;
+                    r.d0 = p[0] | (p[1] << 8) | (p[2] << 16) | ((unsigned)p[3] << 24);
+                    r.d1 = p[4] | (p[5] << 8) | (p[6] << 16) | ((unsigned)p[7] << 24);
+                    r.d2 = p[8] | (p[9] << 8) | (p[10] << 16) | ((unsigned)p[11] << 24);
+                }
+            } else {
+                const uintptr_t a = reinterpret_cast<uintptr_t>(row + c0);
+                const unsigned* p = reinterpret_cast<const unsigned*>(a & ~(uintptr_t)3);
+                r.d0 = alignb(p[1], p[0], (unsigned)(a & 3));
+            }
+        } else if (BGR) {  // pack the 4 reflected pixels into the same 12-byte layout
+            const uint8_t *p0 = row + xr0, *p1 = row + xr1, *p2 = row + xr2, *p3 = row + xr3;
+            r.d0 = p0[0] | (p0[1] << 8) | (p0[2] << 16) | ((unsigned)p1[0] << 24);
+            r.d1 = p1[1] | (p1[2] << 8) | (p2[0] << 16) | ((unsigned)p2[1] << 24);
+            r.d2 = p2[2] | (p3[0] << 8) | (p3[1] << 16) | ((unsigned)p3[2] << 24);
+        } else {
+            r.d0 = row[xr0] | (row[xr1] << 8) | (row[xr2] << 16) | ((unsigned)row[xr3] << 24);
+        }
+        return r;
+    };
+    auto to_grey = [&](const Raw& r) -> unsigned {
+        if (!BGR) return r.d0;
+        const unsigned KH = 7u | (37u << 8) | (19u << 16), KL = 76u | (145u << 8) | (35u << 16);
+        const unsigned g0 = grey_px(r.d0, KH, KL);                       // bytes b0 g0 r0 (x)
+        const unsigned g1 = grey_px(alignb(r.d1, r.d0, 3), KH, KL);      // b1 g1 r1 (x)
+        const unsigned g2 = grey_px(alignb(r.d2, r.d1, 2), KH, KL);      // b2 g2 r2 (x)
+        const unsigned g3 = grey_px(r.d2, KH << 8, KL << 8);             // (x) b3 g3 r3
+        return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    };
+
+    const int qa = Y0 / 2 - 3, qb = (Y1 + 3) / 2 + 1;
+    const int v_first = 2 * qa - 2, v_last = 2 * qb + 2;
+    unsigned ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0;  // horizontal pyrDown sums of the last 5 rows (a | b<<16)
+    unsigned prevP = 0;                      // previous pyramid row for the bottom border
+    unsigned rAe = 0, rAo = 0, rBe = 0, rBo = 0;   // up-sampled pyramid rows q-2, q-1: even columns (r0|r2<<16), odd (r1|r3<<16)
+    unsigned hh[7][4];                       // horizontal Gaussian sums of the last 7 (virtual) rows, newest last
+    unsigned ur0 = 0, ur1 = 0, ur2 = 0, ur3 = 0;  // pyrUp rows, newest last
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) hh[k][j] = 0;
+    unsigned binw = 0;                       // threshold bits of rows y-2, y-1, y: nibbles 0,1,2
+
+    Raw nxt = fetch(v_first);
+    for (int v = v_first; v <= v_last; v++) {
+        const Raw cur = nxt;
+        if (v < v_last) nxt = fetch(v + 1);  // issue the next row's loads before this row's arithmetic
+        const unsigned g = to_grey(cur);
+        if (BGR && o.gray && out_lane && v >= Y0 && v < Y1) {  // rows [Y0,Y1) are real rows, each loaded exactly once
+            uint8_t* q = o.gray + (long long)v * o.gray_stride + c0;
+            if (gray_dword) *reinterpret_cast<unsigned*>(q) = g;
+            else
+                for (int j = 0; j < 4; j++)
+                    if (c0 + j < sw) q[j] = (uint8_t)byte_of(g, j);
+        }
+        {   // horizontal [1 4 6 4 1] at the lane's two even columns c0 and c0+2
+            const unsigned gl = up1(g), gr = down1(g);
+            const unsigned a = dot4(alignb(g, gl, 2), 0x04060401u, byte_of(g, 2));
+            const unsigned b = dot4(g, 0x04060401u, gr & 255u);
+            ph0 = ph1; ph1 = ph2; ph2 = ph3; ph3 = ph4;
+            ph4 = a | (b << 16);
+        }
+        if ((v & 1) || v < v_first + 4) continue;
+        const int q = (v - 2) >> 1;  // pyramid row completed by source row 2q+2
+        us2 P = (as_us2(ph0) + as_us2(ph4) + (as_us2(ph1) + as_us2(ph3)) * (unsigned short)4 + as_us2(ph2) * (unsigned short)6 +
+                 (unsigned short)128) >> (unsigned short)8;
+        if (right_edge) {  // pyrUp right border: column pw stands for column pw-1
+            const unsigned left = up1(as_u32(P));
+            if (k0 + 1 == pw) P.y = P.x;
+            if (k0 == pw) P.x = (unsigned short)(left >> 16);
+        }
+        if (q == ph_) P = as_us2(prevP);       // pyrUp bottom border: row ph stands for row ph-1
+        else if (q < ph_) prevP = as_u32(P);
+        unsigned rCe, rCo;
+        {   // horizontal up-sampling at the lane's 4 columns: even (r0,r2) and odd (r1,r3)
+            const unsigned pk = as_u32(P);
+            const us2 Lv = as_us2(alignb(pk, up1(pk), 2));     // (P[k0-1], P[k0])
+            const us2 Rv = as_us2(alignb(down1(pk), pk, 2));   // (P[k0+1], P[k0+2])
+            rCe = as_u32(Lv + P * (unsigned short)6 + Rv);
+            rCo = as_u32((P + Rv) * (unsigned short)4);
+        }
+        if (q >= qa + 2) {
+            for (int par = 0; par < 2; par++) {
+                const int u = 2 * (q - 1) + par;
+                if (u < 0 || u >= sh) continue;
+                unsigned U4;
+                if (par == 0) {
+                    const us2 e = (as_us2(rAe) + as_us2(rBe) * (unsigned short)6 + as_us2(rCe) + (unsigned short)32) >> (unsigned short)6;
+                    const us2 od = (as_us2(rAo) + as_us2(rBo) * (unsigned short)6 + as_us2(rCo) + (unsigned short)32) >> (unsigned short)6;
+                    U4 = as_u32(e) | (as_u32(od) << 8);
+                } else {
+                    const us2 e = ((as_us2(rBe) + as_us2(rCe)) * (unsigned short)4 + (unsigned short)32) >> (unsigned short)6;
+                    const us2 od = ((as_us2(rBo) + as_us2(rCo)) * (unsigned short)4 + (unsigned short)32) >> (unsigned short)6;
+                    U4 = as_u32(e) | (as_u32(od) << 8);
+                }
+                // BORDER_REPLICATE of the Gaussian: columns < 0 take column 0, columns >= sw take column sw-1
+                if (left_edge) {
+                    const unsigned e = (unsigned)__shfl((int)U4, 4) & 255u;
+                    if (lane < 4) U4 = e * 0x01010101u;
+                }
+                if (right_edge) {
+                    const unsigned e = byte_of((unsigned)__shfl((int)U4, L1 < 0 ? 0 : L1), j1);
+                    if (lane > L1) U4 = e * 0x01010101u;
+                    else if (lane == L1)
+                        for (int j = j1 + 1; j < 4; j++) U4 = (U4 & ~(255u << (8 * j))) | (e << (8 * j));
+                }
+                // horizontal [8 28 56 72 56 28 8] at the lane's 4 columns
+                unsigned H0, H1, H2, H3;
+                {
+                    const unsigned ul = up1(U4), urr = down1(U4);
+                    const unsigned K0 = 8u | (28u << 8) | (56u << 16) | (72u << 24), K1 = 56u | (28u << 8) | (8u << 16);
+                    H0 = dot4(alignb(urr, U4, 1), K1, dot4(alignb(U4, ul, 1), K0, 0));
+                    H1 = dot4(alignb(urr, U4, 2), K1, dot4(alignb(U4, ul, 2), K0, 0));
+                    H2 = dot4(alignb(urr, U4, 3), K1, dot4(alignb(U4, ul, 3), K0, 0));
+                    H3 = dot4(urr, K1, dot4(U4, K0, 0));
+                }
+                // rows above 0 / below sh-1 replicate row 0 / sh-1; one more virtual row flushes the last mask row
+                const int vlo = (u == 0) ? -3 : u, vhi = (u == sh - 1) ? sh + 3 : u;
+                for (int vu = vlo; vu <= vhi; vu++) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) hh[k][j] = hh[k + 1][j];
+                    hh[6][0] = H0; hh[6][1] = H1; hh[6][2] = H2; hh[6][3] = H3;
+                    ur0 = ur1; ur1 = ur2; ur2 = ur3; ur3 = U4;
+                    const int y = vu - 3;
+                    if (y < Y0 - 1 || y > Y1 || y < 0) continue;
+                    unsigned nib = 0;
+                    if (y >= 1 && y <= sh - 2) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const unsigned mean = (8u * (hh[0][j] + hh[6][j]) + 28u * (hh[1][j] + hh[5][j]) + 56u * (hh[2][j] + hh[4][j]) +
+                                                   72u * hh[3][j] + 32768u) >> 16;
+                            nib |= (mean < byte_of(ur0, j) + 8u) ? (1u << j) : 0u;   // src - mean > -8 (ur0 = pyrUp row y)
+                        }
+                        nib &= colmask;
+                    }
+                    binw = (binw >> 4) | (nib << 8);
+                    const int yr = y - 1;
+                    if (yr < Y0 || yr >= Y1) continue;
+                    // 3x3 windows of row yr from threshold rows yr-1, yr, yr+1 and the neighbour lanes' edge bits
+                    const unsigned bl = up1(binw), br = down1(binw);
+                    const unsigned A = ((bl >> 3) & 1u) | ((binw & 15u) << 1) | ((br & 1u) << 5);
+                    const unsigned M = ((bl >> 7) & 1u) | (((binw >> 4) & 15u) << 1) | (((br >> 4) & 1u) << 5);
+                    const unsigned Bw = ((bl >> 11) & 1u) | (((binw >> 8) & 15u) << 1) | (((br >> 8) & 1u) << 5);
+                    const unsigned e0 = lut[(A & 7u) | ((M & 7u) << 3) | ((Bw & 7u) << 6)];
+                    const unsigned e1 = lut[((A >> 1) & 7u) | (((M >> 1) & 7u) << 3) | (((Bw >> 1) & 7u) << 6)];
+                    const unsigned e2 = lut[((A >> 2) & 7u) | (((M >> 2) & 7u) << 3) | (((Bw >> 2) & 7u) << 6)];
+                    const unsigned e3 = lut[((A >> 3) & 7u) | (((M >> 3) & 7u) << 3) | (((Bw >> 3) & 7u) << 6)];
+                    if (out_lane)
+                        *reinterpret_cast<unsigned*>(o.nbr + (long long)yr * o.ns + c0) =
+                            (e0 & 255u) | ((e1 & 255u) << 8) | ((e2 & 255u) << 16) | ((e3 & 255u) << 24);
+                    // plausible border starts (sparse): types of the lane's 4 pixels, 2 bits each
+                    unsigned types = 0;
+                    if (out_lane) {
+                        types = (e0 >> 8) | ((e1 >> 8) << 2) | ((e2 >> 8) << 4) | ((e3 >> 8) << 6);
+                        if (c0 + 3 >= sw) types &= (c0 + 2 >= sw) ? ((c0 + 1 >= sw) ? 0x03u : 0x0fu) : 0x3fu;
+                    }
+                    if (__ballot(types != 0) == 0) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int type = (int)((types >> (2 * j)) & 3u) - 1;
+                        const unsigned long long mask = __ballot(type >= 0);
+                        if (!mask) continue;
+                        const int n = __popcll(mask);
+                        if (staged + n > MARCH_STAGE) flush();
+                        if (type >= 0) stage[staged + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)(yr * o.ns + c0 + j) | ((unsigned)type << 31);
+                        staged += n;
+                    }
                 }
             }
         }
+        rAe = rBe; rAo = rBo;
+        rBe = rCe; rBo = rCo;
     }
-    __syncthreads();
+    flush();
 }
 
-__global__ __launch_bounds__(NT) void binarise_frames_kernel(Workspace ws, const uint8_t* bgr, int row_stride,
-                                                             size_t frame_stride, int grey_in_place) {
-    __shared__ TileLds L;
-    const int tiles_x = (ws.sw + TW - 1) / TW;
+__global__ __launch_bounds__(256) void binarise_frames_kernel(Workspace ws, const uint8_t* bgr, int row_stride, size_t frame_stride) {
+    __shared__ unsigned short lut[512];
+    __shared__ unsigned stage[4][MARCH_STAGE];
+    build_nbr_lut(lut);
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int per_frame = ws.frame_strips * ws.frame_chunks;
+    if (unit >= per_frame * ws.n_frames) return;
+    const int f = unit / per_frame, rem = unit % per_frame;
+    const int chunk = rem / ws.frame_strips, strip = rem % ws.frame_strips;
+    const int Y0 = chunk * ws.frame_chunk_rows;
+    const int Y1 = Y0 + ws.frame_chunk_rows < ws.sh ? Y0 + ws.frame_chunk_rows : ws.sh;
+    MarchOut o;
+    o.gray = ws.gray + (size_t)f * ws.W * ws.H;
+    o.gray_stride = ws.W;
+    o.nbr = ws.nbr_frame + (size_t)f * ws.ns * ws.sh;
+    o.ns = ws.ns;
+    o.roi = f;
+    o.cands = ws.cands_frame;
+    o.n_cands = ws.counters + CNT_FRAME_CANDS;
+    o.cap_cands = ws.cap_frame_cands;
+    o.err = ws.counters + CNT_ERR;
+    march_unit<true>(bgr + (size_t)f * frame_stride, row_stride, ws.sw, ws.sh, strip, Y0, Y1, o, lut, stage[threadIdx.x >> 6]);
+}
+
+// Odd width / height: the last column / row lies outside the even working size (opencvar.cpp:158) but is still
+// greyed by cvarArMultRegistration's BGR2GRAY.
+__global__ __launch_bounds__(256) void grey_edges_kernel(Workspace ws, const uint8_t* bgr, int row_stride, size_t frame_stride) {
     const int f = blockIdx.y;
-    const int X0 = (blockIdx.x % tiles_x) * TW, Y0 = (blockIdx.x / tiles_x) * TH;
     const uint8_t* src = bgr + (size_t)f * frame_stride;
-    binarise_tile<true>(L, src, row_stride, f, ws.W, ws.H, ws.sw, ws.sh, X0, Y0, ws.gray + (size_t)f * ws.W * ws.H, ws.W,
-                        nullptr, ws.nbr_frame + (size_t)f * ws.sw * ws.sh,
-                        ws.cands_frame, ws.counters + CNT_FRAME_CANDS, ws.cap_frame_cands, ws.counters + CNT_ERR);
+    uint8_t* g = ws.gray + (size_t)f * ws.W * ws.H;
+    const int n_col = ws.W > ws.sw ? ws.H : 0, n_row = ws.H > ws.sh ? ws.W : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_col + n_row; i += gridDim.x * blockDim.x) {
+        const int x = i < n_col ? ws.sw : i - n_col, y = i < n_col ? i : ws.sh;
+        const uint8_t* p = src + (long long)y * row_stride + 3 * x;
+        g[(long long)y * ws.W + x] = (uint8_t)grey_of(p[0], p[1], p[2]);
+    }
 }
 
 // The reference greys the caller's frame in place (opencvar.cpp:624-627).  Done as its own pass over the
-// grey plane so that no tile ever reads a half-written BGR pixel of a neighbouring tile's halo.
-__global__ __launch_bounds__(NT) void grey_writeback_kernel(Workspace ws, uint8_t* bgr, int row_stride, size_t frame_stride) {
+// grey plane so that no wave ever reads a half-written BGR pixel of a neighbouring strip's halo.
+__global__ __launch_bounds__(256) void grey_writeback_kernel(Workspace ws, uint8_t* bgr, int row_stride, size_t frame_stride) {
     const int f = blockIdx.y;
     const uint8_t* g = ws.gray + (size_t)f * ws.W * ws.H;
     uint8_t* dst = bgr + (size_t)f * frame_stride;
     const long long n = (long long)ws.W * ws.H;
-    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % ws.W), y = (int)(i / ws.W);
         const uint8_t v = g[i];
         uint8_t* q = dst + (long long)y * row_stride + 3 * x;
@@ -246,33 +366,45 @@ __global__ __launch_bounds__(NT) void grey_writeback_kernel(Workspace ws, uint8_
     }
 }
 
-__global__ __launch_bounds__(NT) void binarise_crops_kernel(Workspace ws) {
-    __shared__ TileLds L;
-    int n_tiles = ws.counters[CNT_CROP_TILES];
-    if (n_tiles > ws.cap_crop_tiles) n_tiles = ws.cap_crop_tiles;
-    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const TileDesc td = ws.tiles_crop[t];
+__global__ __launch_bounds__(256) void binarise_crops_kernel(Workspace ws) {
+    __shared__ unsigned short lut[512];
+    __shared__ unsigned stage[4][MARCH_STAGE];
+    build_nbr_lut(lut);
+    int n_units = ws.counters[CNT_CROP_TILES];
+    if (n_units > ws.cap_crop_tiles) n_units = ws.cap_crop_tiles;
+    for (int u = blockIdx.x * 4 + (threadIdx.x >> 6); u < n_units; u += gridDim.x * 4) {
+        const TileDesc td = ws.tiles_crop[u];
         const Roi r = ws.rois_crop[td.roi];
         const uint8_t* src = ws.gray + (size_t)r.frame * ws.W * ws.H + (size_t)r.y0 * ws.W + r.x0;
-        binarise_tile<false>(L, src, ws.W, td.roi, r.w, r.h, r.sw, r.sh, td.x0, td.y0, nullptr, 0, nullptr,
-                             ws.nbr_crop + r.nbr_off, ws.cands_crop, ws.counters + CNT_CROP_CANDS, ws.cap_crop_cands,
-                             ws.counters + CNT_ERR);
+        const int Y1 = td.y0 + MARCH_CROP_ROWS < r.sh ? td.y0 + MARCH_CROP_ROWS : r.sh;
+        MarchOut o;
+        o.gray = nullptr;
+        o.gray_stride = 0;
+        o.nbr = ws.nbr_crop + r.nbr_off;
+        o.ns = r.ns;
+        o.roi = td.roi;
+        o.cands = ws.cands_crop;
+        o.n_cands = ws.counters + CNT_CROP_CANDS;
+        o.cap_cands = ws.cap_crop_cands;
+        o.err = ws.counters + CNT_ERR;
+        march_unit<false>(src, ws.W, r.sw, r.sh, td.x0, td.y0, Y1, o, lut, stage[threadIdx.x >> 6]);
     }
 }
 
 void launch_binarise_frames(const Workspace& ws, const uint8_t* d_bgr, int row_stride, size_t frame_stride, int grey_in_place,
                             hipStream_t stream) {
-    const int tiles = ((ws.sw + TW - 1) / TW) * ((ws.sh + TH - 1) / TH);
-    if (tiles <= 0 || ws.n_frames <= 0) return;
-    hipLaunchKernelGGL(binarise_frames_kernel, dim3(tiles, ws.n_frames), dim3(NT), 0, stream, ws, d_bgr, row_stride, frame_stride,
-                       grey_in_place);
+    const int units = ws.frame_strips * ws.frame_chunks * ws.n_frames;
+    if (units <= 0) return;
+    hipLaunchKernelGGL(binarise_frames_kernel, dim3((units + 3) / 4), dim3(256), 0, stream, ws, d_bgr, row_stride, frame_stride);
+    if (ws.W > ws.sw || ws.H > ws.sh)
+        hipLaunchKernelGGL(grey_edges_kernel, dim3(8, ws.n_frames), dim3(256), 0, stream, ws, d_bgr, row_stride, frame_stride);
     if (grey_in_place)
-        hipLaunchKernelGGL(grey_writeback_kernel, dim3(1024, ws.n_frames), dim3(NT), 0, stream, ws, const_cast<uint8_t*>(d_bgr),
+        hipLaunchKernelGGL(grey_writeback_kernel, dim3(1024, ws.n_frames), dim3(256), 0, stream, ws, const_cast<uint8_t*>(d_bgr),
                            row_stride, frame_stride);
 }
 
 void launch_binarise_crops(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(binarise_crops_kernel, dim3(2048), dim3(NT), 0, stream, ws);
+    hipLaunchKernelGGL(binarise_crops_kernel, dim3(2048), dim3(256), 0, stream, ws);
 }
 
 }  // namespace ocvar

@@ -13,15 +13,15 @@ namespace ocvar {
 
 template <bool CROP>
 __device__ __forceinline__ void follow_one(const Workspace& ws, const StartCand c) {
-    int sw, sh, img_w, img_h;
+    int sw, sh, img_w, img_h;   // sw: row stride of the neighbour plane (positions are y*stride + x)
     const uint8_t* nbr;
     if (CROP) {
         const Roi r = ws.rois_crop[c.roi];
-        sw = r.sw; sh = r.sh; img_w = r.w; img_h = r.h;
+        sw = r.ns; sh = r.sh; img_w = r.w; img_h = r.h;
         nbr = ws.nbr_crop + r.nbr_off;
     } else {
-        sw = ws.sw; sh = ws.sh; img_w = ws.W; img_h = ws.H;
-        nbr = ws.nbr_frame + (size_t)c.roi * ws.sw * ws.sh;
+        sw = ws.ns; sh = ws.sh; img_w = ws.W; img_h = ws.H;
+        nbr = ws.nbr_frame + (size_t)c.roi * ws.ns * ws.sh;
     }
     const int plane = sw * sh;
     if (c.pos <= 0 || c.pos >= plane) return;
@@ -126,12 +126,12 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
         }
         int x0, y0, cw, ch, roi_index = -1;
         crop_rect(quad, ws.W, ws.H, &x0, &y0, &cw, &ch);
-        const int sw = cw & ~1, sh = ch & ~1;
+        const int sw = cw & ~1, sh = ch & ~1, ns = (sw + 3) & ~3;
         if (sw >= 2 && sh >= 2) {
             const int r = atomicAdd(ws.counters + CNT_CROP_ROIS, 1);
-            const long long plane = (long long)sw * sh;
+            const long long plane = (long long)ns * sh;
             const long long off = (long long)atomicAdd(ws.crop_pixels, (unsigned long long)plane);
-            const int ntx = (sw + TILE_W - 1) / TILE_W, nty = (sh + TILE_H - 1) / TILE_H;
+            const int ntx = (sw + MARCH_STRIP - 1) / MARCH_STRIP, nty = (sh + MARCH_CROP_ROWS - 1) / MARCH_CROP_ROWS;
             if (r >= ws.cap_crop_rois || off + plane > ws.cap_crop_pixels) {
                 atomicOr(ws.counters + CNT_ERR, ERR_CROP_OVERFLOW);
             } else {
@@ -140,13 +140,13 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
                     atomicOr(ws.counters + CNT_ERR, ERR_TILE_OVERFLOW);
                 } else {
                     Roi roi;
-                    roi.frame = f; roi.x0 = x0; roi.y0 = y0; roi.w = cw; roi.h = ch; roi.sw = sw; roi.sh = sh;
+                    roi.frame = f; roi.x0 = x0; roi.y0 = y0; roi.w = cw; roi.h = ch; roi.sw = sw; roi.sh = sh; roi.ns = ns;
                     roi.owner = i; roi.nbr_off = off;
                     ws.rois_crop[r] = roi;
                     ws.best_crop[r] = ~0ull;
                     for (int t = 0; t < ntx * nty; t++) {
                         TileDesc td;
-                        td.roi = r; td.x0 = (t % ntx) * TILE_W; td.y0 = (t / ntx) * TILE_H;
+                        td.roi = r; td.x0 = t % ntx; td.y0 = (t / ntx) * MARCH_CROP_ROWS;
                         ws.tiles_crop[tbase + t] = td;
                     }
                     roi_index = r;

@@ -31,6 +31,7 @@ struct Roi {
     int x0, y0;       // origin inside the frame's gray plane
     int w, h;         // ROI size (img->width/height for the border rule, opencvar.cpp:204-206)
     int sw, sh;       // w & ~1, h & ~1 (opencvar.cpp:158): size of the binary / neighbour plane
+    int ns;           // row stride of the neighbour plane (sw rounded up to a multiple of 4)
     int owner;        // frame pass: frame index; crop pass: index of the frame-pass quad it came from
     long long nbr_off;  // offset of this ROI's neighbour-mask plane in the pass's pool
 };
@@ -38,7 +39,7 @@ struct Roi {
 // A candidate border start found by the binarise kernel.
 struct StartCand {
     int roi;
-    int pos;          // scan position y*sw + x at which cvFindContours would discover the border
+    int pos;          // scan position y*ns + x (ns = plane row stride) at which cvFindContours would discover the border
     int is_hole;
 };
 

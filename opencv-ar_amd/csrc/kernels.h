@@ -11,14 +11,16 @@ namespace ocvar {
 constexpr int MAXQ = OCVAR_MAX_QUADS;      // frame-pass quads kept per frame
 constexpr int MAXM = OCVAR_MAX_MARKERS;    // markers kept per frame (tracked + new)
 constexpr int MAXT = OCVAR_MAX_TEMPLATES;
-constexpr int TILE_W = 64, TILE_H = 32;    // output tile of the binarise kernel
+constexpr int MARCH_STRIP = 224;           // output columns of one wave's strip in the binarise kernel (256 loaded)
+constexpr int MARCH_CROP_ROWS = 256;       // rows per work unit in the crop pass (even)
+constexpr int MARCH_STAGE = 512;           // border starts a wave stages in LDS between two appends to the global list
 constexpr int BACK_STEPS = 32;             // backward look of an outer start before it follows its border
 
 // error bits accumulated in Workspace::err[0]
 enum { ERR_CAND_OVERFLOW = 1, ERR_POOL_OVERFLOW = 2, ERR_QUAD_OVERFLOW = 4, ERR_TRACE_OVERRUN = 8, ERR_CROP_OVERFLOW = 16,
        ERR_TILE_OVERFLOW = 32 };
 
-struct TileDesc { int roi, x0, y0; };
+struct TileDesc { int roi, x0, y0; };   // binarise work unit of the crop pass: x0 = strip index, y0 = first row
 
 struct CandRec {   // pre-dedupe candidate, slot [frame][quad][template]
     int valid, orient;
@@ -38,7 +40,8 @@ struct Workspace {
     int cap_frame_cands, cap_crop_cands, cap_crop_rois, cap_crop_tiles, cap_crop_quads;
     long long cap_pool_ints, cap_crop_pixels;
     // per batch geometry
-    int W, H, sw, sh, n_frames, n_templates;
+    int W, H, sw, sh, ns, n_frames, n_templates;   // ns: row stride of a neighbour-mask plane = sw rounded up to 4
+    int frame_strips, frame_chunks, frame_chunk_rows;  // binarise work decomposition of a frame
     // device buffers
     uint8_t* gray;          // [B][H][W]
     uint8_t* nbr_frame;     // [B][sh][sw]
