@@ -6,6 +6,7 @@
 // There is deliberately no CPU path here: if the device or the code object is missing, create() fails.
 #include "kernels.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -82,14 +83,19 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     w.cap_crop_tiles = (int)std::min<size_t>(B * 4096, (size_t)1 << 30);
     w.cap_crop_quads = (int)(B * MAXQ * 4);
     w.cap_pool_ints = (long long)B * (1 << 20);
-    w.cap_crop_pixels = (long long)(2 * B * (size_t)(max_width + 4) * max_height);
+    w.cap_crop_pixels = (long long)(2 * B * (size_t)(max_width + 16) * max_height);
     int rc;
     if ((rc = dev_alloc(c, &w.gray, B * WH))) return rc;
-    if ((rc = dev_alloc(c, &w.nbr_frame, B * (size_t)(max_width + 4) * max_height))) return rc;
+    if ((rc = dev_alloc(c, &w.nbr_frame, B * (size_t)(max_width + 16) * max_height))) return rc;
     if ((rc = dev_alloc(c, &w.nbr_crop, (size_t)w.cap_crop_pixels))) return rc;
     if ((rc = dev_alloc(c, &w.cands_frame, (size_t)w.cap_frame_cands))) return rc;
     if ((rc = dev_alloc(c, &w.cands_crop, (size_t)w.cap_crop_cands))) return rc;
     if ((rc = dev_alloc(c, &w.pool, (size_t)w.cap_pool_ints))) return rc;
+    w.cap_long = (int)std::min<size_t>(B * 4096, (size_t)1 << 28);
+    if ((rc = dev_alloc(c, &w.mid_frame, (size_t)w.cap_long))) return rc;
+    if ((rc = dev_alloc(c, &w.mid_crop, (size_t)w.cap_long))) return rc;
+    if ((rc = dev_alloc(c, &w.long_frame, (size_t)w.cap_long))) return rc;
+    if ((rc = dev_alloc(c, &w.long_crop, (size_t)w.cap_long))) return rc;
     if ((rc = dev_alloc(c, &w.quads_frame, B * MAXQ))) return rc;
     if ((rc = dev_alloc(c, &w.n_quads_frame, B))) return rc;
     if ((rc = dev_alloc(c, &w.squares, B * MAXQ * 8))) return rc;
@@ -169,8 +175,11 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     w.H = height;
     w.sw = width & ~1;
     w.sh = height & ~1;
-    w.ns = (w.sw + 3) & ~3;
+    w.ns = (w.sw + 15) & ~15;
     w.n_frames = n_frames;
+    w.mid_steps = std::getenv("OCVAR_MID_STEPS") ? std::atoi(std::getenv("OCVAR_MID_STEPS")) : MID_STEPS;
+    w.long_blocks = std::getenv("OCVAR_LONG_BLOCKS") ? std::atoi(std::getenv("OCVAR_LONG_BLOCKS")) : 1024;
+    w.dbg_follow_stop = std::getenv("OCVAR_DBG_FOLLOW_STOP") ? std::atoi(std::getenv("OCVAR_DBG_FOLLOW_STOP")) : 0;
     w.frame_strips = (w.sw + MARCH_STRIP - 1) / MARCH_STRIP;
     {   // rows per binarise work unit: about 128, even, chunks of equal size
         int chunks = (w.sh + 64) / 128;
@@ -192,6 +201,8 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     launch_binarise_frames(w, d_bgr, row_stride, frame_stride, grey_in_place, s);
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     launch_follow_frames(w, s);
+    launch_follow_mid_frames(w, s);
+    launch_follow_long_frames(w, s);
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
     launch_order_and_crops(w, s);
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
@@ -199,6 +210,8 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
         launch_binarise_crops(w, s);
         HIP_TRY(c, hipEventRecord(c->ev[4], s));
         launch_follow_crops(w, s);
+        launch_follow_mid_crops(w, s);
+        launch_follow_long_crops(w, s);
         HIP_TRY(c, hipEventRecord(c->ev[5], s));
         launch_decode(w, s);
         HIP_TRY(c, hipEventRecord(c->ev[6], s));

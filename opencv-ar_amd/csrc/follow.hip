@@ -11,40 +11,34 @@
 
 namespace ocvar {
 
-template <bool CROP>
-__device__ __forceinline__ void follow_one(const Workspace& ws, const StartCand c) {
-    int sw, sh, img_w, img_h;   // sw: row stride of the neighbour plane (positions are y*stride + x)
+// geometry of the ROI a start belongs to
+struct PlaneRef {
     const uint8_t* nbr;
+    int ns, sh, img_w, img_h, plane;
+};
+
+template <bool CROP>
+__device__ __forceinline__ PlaneRef plane_of(const Workspace& ws, int roi) {
+    PlaneRef p;
     if (CROP) {
-        const Roi r = ws.rois_crop[c.roi];
-        sw = r.ns; sh = r.sh; img_w = r.w; img_h = r.h;
-        nbr = ws.nbr_crop + r.nbr_off;
+        const Roi r = ws.rois_crop[roi];
+        p.ns = r.ns; p.sh = r.sh; p.img_w = r.w; p.img_h = r.h;
+        p.nbr = ws.nbr_crop + r.nbr_off;
     } else {
-        sw = ws.ns; sh = ws.sh; img_w = ws.W; img_h = ws.H;
-        nbr = ws.nbr_frame + (size_t)c.roi * ws.ns * ws.sh;
+        p.ns = ws.ns; p.sh = ws.sh; p.img_w = ws.W; p.img_h = ws.H;
+        p.nbr = ws.nbr_frame + (size_t)roi * ws.ns * ws.sh;
     }
-    const int plane = sw * sh;
-    if (c.pos <= 0 || c.pos >= plane) return;
-    if (!c.is_hole && earlier_start_behind(nbr, sw, plane, c.pos, 0, BACK_STEPS)) return;
-    const int max_steps = 4 * plane + 16;
-    const TraceStats st = trace_border<false>(nbr, sw, plane, c.pos, c.is_hole, nullptr, 0, max_steps);
-    if (st.status == TRACE_OVERRUN) {
-        atomicOr(ws.counters + CNT_ERR, ERR_TRACE_OVERRUN);
-        return;
-    }
-    if (!worth_approximating(st)) return;
-    const int need = 2 * st.npts + 2 * (st.npts + 2);
-    const long long off = atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
-    if (off + need > ws.cap_pool_ints) {
-        atomicOr(ws.counters + CNT_ERR, ERR_POOL_OVERFLOW);
-        return;
-    }
-    int* pts = ws.pool + off;
-    DpSlice* stack = reinterpret_cast<DpSlice*>(pts + 2 * st.npts);
-    trace_border<true>(nbr, sw, plane, c.pos, c.is_hole, pts, st.npts, max_steps);
+    p.plane = p.ns * p.sh;
+    return p;
+}
+
+// Douglas-Peucker + quad filter on stored points, then publication of the quad (one lane).
+template <bool CROP>
+__device__ __forceinline__ void approximate_and_emit(const Workspace& ws, const StartCand c, const PlaneRef& pl, const int* pts,
+                                                     int npts, double perimeter, DpSlice* stack) {
     int dst[2 * (DP_MAX_OUT + 1)];
-    const int m = approx_poly_dp(pts, st.npts, st.perimeter * 0.02, dst, stack);
-    if (m != 4 || !quad_filter(dst, img_w, img_h)) return;
+    const int m = approx_poly_dp(pts, npts, perimeter * 0.02, dst, stack);
+    if (m != 4 || !quad_filter(dst, pl.img_w, pl.img_h)) return;
     QuadRec q;
     q.roi = c.roi;
     q.start = c.pos;
@@ -68,13 +62,42 @@ __device__ __forceinline__ void follow_one(const Workspace& ws, const StartCand 
     }
 }
 
-template <bool CROP>
+// Tiers 1 and 2, one lane per start, mask bytes read from global memory (one memory latency per step, 64 borders
+// per wave in flight).  Tier 1 sees every plausible start with a small step budget: most drop out or close within a
+// few steps (noise, staircase false starts).  Tier 2 re-follows the survivors of tier 1 -- now densely packed, a few
+// hundred steps each -- with a larger budget.  What outlives tier 2 (image-sized borders) goes to tier 3.
+// Returns true when the start must be queued for the next tier.
+template <bool CROP, int TIER>
+__device__ __forceinline__ bool follow_short(const Workspace& ws, const StartCand c) {
+    const int BUDGET = TIER == 1 ? SHORT_STEPS : ws.mid_steps;
+    const PlaneRef pl = plane_of<CROP>(ws, c.roi);
+    if (c.pos <= 0 || c.pos >= pl.plane) return false;
+    if (TIER == 1 && !c.is_hole && earlier_start_behind(pl.nbr, pl.ns, pl.plane, c.pos, 0, BACK_STEPS)) return false;
+    const TraceStats st = trace_border<false, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
+    if (st.status == TRACE_OVERRUN) return true;  // budget exhausted: a long border
+    if (!worth_approximating(st) || ws.dbg_follow_stop == 1) return false;
+    const int need = 2 * st.npts + 2 * (st.npts + 2);
+    const long long off = atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
+    if (off + need > ws.cap_pool_ints) {
+        atomicOr(ws.counters + CNT_ERR, ERR_POOL_OVERFLOW);
+        return false;
+    }
+    int* pts = ws.pool + off;
+    trace_border<true, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, pts, st.npts, BUDGET);
+    if (ws.dbg_follow_stop == 2) return false;
+    approximate_and_emit<CROP>(ws, c, pl, pts, st.npts, st.perimeter, reinterpret_cast<DpSlice*>(pts + 2 * st.npts));
+    return false;
+}
+
+template <bool CROP, int TIER>
 __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
-    const StartCand* cands = CROP ? ws.cands_crop : ws.cands_frame;
-    int n = ws.counters[CROP ? CNT_CROP_CANDS : CNT_FRAME_CANDS];
-    const int cap = CROP ? ws.cap_crop_cands : ws.cap_frame_cands;
+    const StartCand* cands = TIER == 1 ? (CROP ? ws.cands_crop : ws.cands_frame) : (CROP ? ws.mid_crop : ws.mid_frame);
+    StartCand* longs = TIER == 1 ? (CROP ? ws.mid_crop : ws.mid_frame) : (CROP ? ws.long_crop : ws.long_frame);
+    int n = ws.counters[TIER == 1 ? (CROP ? CNT_CROP_CANDS : CNT_FRAME_CANDS) : (CROP ? CNT_MID_C : CNT_MID_F)];
+    const int cap = TIER == 1 ? (CROP ? ws.cap_crop_cands : ws.cap_frame_cands) : ws.cap_long;
     if (n > cap) n = cap;
-    int* ticket = ws.counters + (CROP ? CNT_TICKET_C : CNT_TICKET_F);
+    int* ticket = ws.counters + (TIER == 1 ? (CROP ? CNT_TICKET_C : CNT_TICKET_F) : (CROP ? CNT_TICKET_MC : CNT_TICKET_MF));
+    int* n_long = ws.counters + (TIER == 1 ? (CROP ? CNT_MID_C : CNT_MID_F) : (CROP ? CNT_LONG_C : CNT_LONG_F));
     const int lane = threadIdx.x & 63;
     for (;;) {
         int base = 0;
@@ -82,7 +105,240 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
         base = __shfl(base, 0);
         if (base >= n) break;
         const int idx = base + lane;
-        if (idx < n) follow_one<CROP>(ws, cands[idx]);
+        StartCand c;
+        c.roi = 0; c.pos = 0; c.is_hole = 0;
+        bool queue = false;
+        if (idx < n) {
+            c = cands[idx];
+            queue = follow_short<CROP, TIER>(ws, c);
+        }
+        const unsigned long long mask = __ballot(queue);
+        if (mask) {
+            int qbase = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if (lane == leader) qbase = atomicAdd(n_long, __popcll(mask));
+            qbase = __shfl(qbase, leader);
+            if (queue) {
+                const int slot = qbase + __popcll(mask & ((1ull << lane) - 1ull));
+                if (slot < ws.cap_long) longs[slot] = c;
+                else atomicOr(ws.counters + CNT_ERR, ERR_CAND_OVERFLOW);
+            }
+        }
+    }
+}
+
+// ---- Phase B: one wave per long border, walking inside an LDS tile cache -------------------------------------
+// The follower's step needs the neighbour mask of the pixel it just moved to: a dependent byte load, i.e. one
+// HBM/L2 latency per step when done from global memory.  Here the wave cooperatively copies a TILE x TILE window
+// of the mask plane around the current pixel into LDS (each lane one row, 16-byte loads) and all lanes walk the
+// same border redundantly (wave-uniform control flow), so a step costs an LDS read; the window is re-centred when
+// the walk leaves it.  Same stepping rules as trace_core.h::trace_border.
+struct TileCache {
+    uint8_t* lds;          // TILE*TILE bytes of this wave
+    const uint8_t* nbr;
+    int ns, sh;            // ns is a multiple of 16, the plane base is 16-byte aligned
+    int tx0, ty0;          // window origin (tx0 multiple of 16, may be negative)
+};
+
+// (bx,by): direction of travel; the window is pushed ahead so that a straight run re-centres as rarely as possible
+__device__ __forceinline__ void tile_load(TileCache& t, int x, int y, int bx = 0, int by = 0) {
+    const int lane = threadIdx.x & 63;
+    t.tx0 = (x + 20 * bx - TILE / 2 + 8) & ~15;   // keeps x-20..x+27 inside for bx = 0, up to 55 pixels ahead otherwise
+    t.ty0 = y + 28 * by - TILE / 2;
+    const int row = t.ty0 + lane;
+    uint4* dst = reinterpret_cast<uint4*>(t.lds + lane * TILE);
+#pragma unroll
+    for (int cch = 0; cch < TILE / 16; cch++) {
+        const int cx = t.tx0 + 16 * cch;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row >= 0 && row < t.sh && cx >= 0 && cx + 16 <= t.ns) v = *reinterpret_cast<const uint4*>(t.nbr + (long long)row * t.ns + cx);
+        dst[cch] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+}
+
+__device__ __forceinline__ unsigned tile_get(TileCache& t, int x, int y) {
+    if ((unsigned)(x - t.tx0) >= (unsigned)TILE || (unsigned)(y - t.ty0) >= (unsigned)TILE) tile_load(t, x, y);
+    return t.lds[(y - t.ty0) * TILE + (x - t.tx0)];
+}
+
+template <bool STORE>
+__device__ TraceStats trace_border_tiled(TileCache& t, int cpos, int is_hole, int* out, int max_pts, int max_steps) {
+    const int lane = threadIdx.x & 63;
+    TraceStats st;
+    st.status = TRACE_OK;
+    st.npts = 0;
+    st.minx = st.miny = 0x7fffffff;
+    st.maxx = st.maxy = -0x7fffffff;
+    st.perimeter = 0.0;
+    const int ns = t.ns;
+    const int i0 = cpos - is_hole;
+    const int x0 = i0 % ns, y0 = i0 / ns;
+    int x = x0, y = y0;
+    unsigned m = tile_get(t, x, y);
+    if (m == 0) {
+        st.status = TRACE_SINGLE;
+        st.npts = 1;
+        return st;
+    }
+    int s = first_cw(m, (is_hole ? 0 : 4) - 1);
+    const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
+    int prev_s = s ^ 4;
+    int fx = 0, fy = 0, lx = 0, ly = 0;
+    for (int step = 0;; step++) {
+        if (step >= max_steps) {
+            st.status = TRACE_OVERRUN;
+            return st;
+        }
+        const int s_end = s;
+        s = first_ccw(m, s_end + 1);
+        const int examined = (s - (s_end + 1)) & 7;
+        const int i3 = y * ns + x;
+        if ((((4 - (s_end + 1)) & 7) < examined && i3 < cpos) || (((0 - (s_end + 1)) & 7) < examined && i3 + 1 < cpos)) {
+            st.status = TRACE_NOT_FIRST;
+            return st;
+        }
+        if (s != prev_s) {
+            if (st.npts == 0) {
+                fx = x;
+                fy = y;
+            } else {
+                const float dx = (float)x - (float)lx, dy = (float)y - (float)ly;
+                st.perimeter += (double)sqrt_rn(dx * dx + dy * dy);
+            }
+            lx = x;
+            ly = y;
+            st.minx = x < st.minx ? x : st.minx;
+            st.maxx = x > st.maxx ? x : st.maxx;
+            st.miny = y < st.miny ? y : st.miny;
+            st.maxy = y > st.maxy ? y : st.maxy;
+            if (STORE && st.npts < max_pts && lane == 0) {
+                out[2 * st.npts] = x;
+                out[2 * st.npts + 1] = y;
+            }
+            st.npts++;
+            prev_s = s;
+        }
+        const int px = x, py = y;
+        const int ddx = dir_dx(s), ddy = dir_dy(s);
+        x += ddx;
+        y += ddy;
+        if (x == x0 && y == y0 && px == x1 && py == y1) break;
+        if ((unsigned)x >= (unsigned)ns || (unsigned)y >= (unsigned)t.sh) {
+            st.status = TRACE_OVERRUN;
+            return st;
+        }
+        unsigned m4 = tile_get(t, x, y);
+        if (m4 == 0) {
+            st.status = TRACE_OVERRUN;
+            return st;
+        }
+        if (s == ((s_end + 4) & 7) && m4 == m) {
+            // Straight run (see trace_core.h): every further pixel with this mask leaves in direction s again.  The 64
+            // lanes look at the next 64 pixels of the line at once; the first lane that sees another mask, the end of
+            // the window, or the closing step decides how far the walk jumps.
+            const bool w_ex = ((4 - (s_end + 1)) & 7) < examined, e_ex = ((0 - (s_end + 1)) & 7) < examined;
+            bool closed = false;
+            for (;;) {
+                const int qx = x + (lane + 1) * ddx, qy = y + (lane + 1) * ddy;
+                const bool in_tile = (unsigned)(qx - t.tx0) < (unsigned)TILE && (unsigned)(qy - t.ty0) < (unsigned)TILE;
+                const unsigned mq = in_tile ? t.lds[(qy - t.ty0) * TILE + (qx - t.tx0)] : 256u;
+                const bool closes = qx == x0 && qy == y0 && qx - ddx == x1 && qy - ddy == y1;
+                const unsigned long long stop = __ballot(closes || mq != m);
+                const int k = stop ? __ffsll((long long)stop) - 1 : 64;   // pixels (x,y)+1..k carry mask m
+                // scan positions of the pixels passed: monotonic along a line, so the two ends decide
+                const int pa = y * ns + x, pb = (y + k * ddy) * ns + x + k * ddx;
+                if ((w_ex && (pa < cpos || pb < cpos)) || (e_ex && (pa + 1 < cpos || pb + 1 < cpos))) {
+                    st.status = TRACE_NOT_FIRST;
+                    return st;
+                }
+                x += k * ddx;
+                y += k * ddy;
+                step += k;
+                if (step >= max_steps) {
+                    st.status = TRACE_OVERRUN;
+                    return st;
+                }
+                if (k == 64) continue;
+                const int stop_closes = __shfl((int)closes, k);
+                const unsigned stop_m = (unsigned)__shfl((int)mq, k);
+                if (stop_closes) {
+                    closed = true;
+                    break;
+                }
+                if (stop_m == 256u) {  // end of the window: re-centre ahead and keep running
+                    if ((unsigned)(x + ddx) >= (unsigned)ns || (unsigned)(y + ddy) >= (unsigned)t.sh) {
+                        st.status = TRACE_OVERRUN;
+                        return st;
+                    }
+                    tile_load(t, x + ddx, y + ddy, ddx, ddy);
+                    continue;
+                }
+                x += ddx;   // land on the first pixel with a different mask
+                y += ddy;
+                step++;
+                m4 = stop_m;
+                break;
+            }
+            if (closed) break;
+            if (m4 == 0) {
+                st.status = TRACE_OVERRUN;
+                return st;
+            }
+        }
+        m = m4;
+        s = (s + 4) & 7;
+    }
+    if (st.npts > 1) {
+        const float dx = (float)fx - (float)lx, dy = (float)fy - (float)ly;
+        st.perimeter += (double)sqrt_rn(dx * dx + dy * dy);
+    }
+    return st;
+}
+
+template <bool CROP>
+__global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[4][TILE * TILE];
+    const StartCand* longs = CROP ? ws.long_crop : ws.long_frame;
+    int n = ws.counters[CROP ? CNT_LONG_C : CNT_LONG_F];
+    if (n > ws.cap_long) n = ws.cap_long;
+    int* ticket = ws.counters + (CROP ? CNT_TICKET_LC : CNT_TICKET_LF);
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        int idx = 0;
+        if (lane == 0) idx = atomicAdd(ticket, 1);
+        idx = __shfl(idx, 0);
+        if (idx >= n) break;
+        const StartCand c = longs[idx];
+        const PlaneRef pl = plane_of<CROP>(ws, c.roi);
+        TileCache t;
+        t.lds = tiles[threadIdx.x >> 6];
+        t.nbr = pl.nbr;
+        t.ns = pl.ns;
+        t.sh = pl.sh;
+        t.tx0 = t.ty0 = -(1 << 28);
+        const int max_steps = 4 * pl.plane + 16;
+        const TraceStats st = trace_border_tiled<false>(t, c.pos, c.is_hole, nullptr, 0, max_steps);
+        if (st.status == TRACE_OVERRUN) {
+            if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TRACE_OVERRUN);
+            continue;
+        }
+        if (!worth_approximating(st) || ws.dbg_follow_stop == 1) continue;
+        const int need = 2 * st.npts + 2 * (st.npts + 2);
+        long long off = 0;
+        if (lane == 0) off = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
+        off = (long long)(unsigned)__shfl((int)(off & 0xffffffffll), 0) | ((long long)__shfl((int)(off >> 32), 0) << 32);
+        if (off + need > ws.cap_pool_ints) {
+            if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_POOL_OVERFLOW);
+            continue;
+        }
+        int* pts = ws.pool + off;
+        trace_border_tiled<true>(t, c.pos, c.is_hole, pts, st.npts, max_steps);
+        if (ws.dbg_follow_stop == 2) continue;
+        if (lane == 0) {
+            __threadfence_block();
+            approximate_and_emit<CROP>(ws, c, pl, pts, st.npts, st.perimeter, reinterpret_cast<DpSlice*>(pts + 2 * st.npts));
+        }
     }
 }
 
@@ -126,7 +382,7 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
         }
         int x0, y0, cw, ch, roi_index = -1;
         crop_rect(quad, ws.W, ws.H, &x0, &y0, &cw, &ch);
-        const int sw = cw & ~1, sh = ch & ~1, ns = (sw + 3) & ~3;
+        const int sw = cw & ~1, sh = ch & ~1, ns = (sw + 15) & ~15;
         if (sw >= 2 && sh >= 2) {
             const int r = atomicAdd(ws.counters + CNT_CROP_ROIS, 1);
             const long long plane = (long long)ns * sh;
@@ -158,10 +414,22 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
 }
 
 void launch_follow_frames(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(follow_kernel<false>, dim3(1024), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL((follow_kernel<false, 1>), dim3(1024), dim3(256), 0, stream, ws);
 }
 void launch_follow_crops(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(follow_kernel<true>, dim3(1024), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL((follow_kernel<true, 1>), dim3(1024), dim3(256), 0, stream, ws);
+}
+void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream) {
+    hipLaunchKernelGGL((follow_kernel<false, 2>), dim3(1024), dim3(256), 0, stream, ws);
+}
+void launch_follow_mid_crops(const Workspace& ws, hipStream_t stream) {
+    hipLaunchKernelGGL((follow_kernel<true, 2>), dim3(1024), dim3(256), 0, stream, ws);
+}
+void launch_follow_long_frames(const Workspace& ws, hipStream_t stream) {
+    hipLaunchKernelGGL(follow_long_kernel<false>, dim3(ws.long_blocks), dim3(256), 0, stream, ws);
+}
+void launch_follow_long_crops(const Workspace& ws, hipStream_t stream) {
+    hipLaunchKernelGGL(follow_long_kernel<true>, dim3(ws.long_blocks), dim3(256), 0, stream, ws);
 }
 void launch_order_and_crops(const Workspace& ws, hipStream_t stream) {
     if (ws.n_frames > 0) hipLaunchKernelGGL(order_and_crops_kernel, dim3(ws.n_frames), dim3(256), 0, stream, ws);

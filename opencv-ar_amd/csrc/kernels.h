@@ -14,7 +14,10 @@ constexpr int MAXT = OCVAR_MAX_TEMPLATES;
 constexpr int MARCH_STRIP = 224;           // output columns of one wave's strip in the binarise kernel (256 loaded)
 constexpr int MARCH_CROP_ROWS = 256;       // rows per work unit in the crop pass (even)
 constexpr int MARCH_STAGE = 512;           // border starts a wave stages in LDS between two appends to the global list
-constexpr int BACK_STEPS = 32;             // backward look of an outer start before it follows its border
+constexpr int BACK_STEPS = 32;
+constexpr int SHORT_STEPS = 96;            // step budget of follower tier 1 (every plausible start, one lane each)
+constexpr int MID_STEPS = 3072;            // step budget of tier 2 (borders that outlived tier 1, one lane each); the rest: tier 3, one wave each
+constexpr int TILE = 64;                   // side of the LDS tile the wave-per-border follower walks in             // backward look of an outer start before it follows its border
 
 // error bits accumulated in Workspace::err[0]
 enum { ERR_CAND_OVERFLOW = 1, ERR_POOL_OVERFLOW = 2, ERR_QUAD_OVERFLOW = 4, ERR_TRACE_OVERRUN = 8, ERR_CROP_OVERFLOW = 16,
@@ -32,7 +35,8 @@ struct CandRec {   // pre-dedupe candidate, slot [frame][quad][template]
 // counters block (device ints), zeroed at the start of every batch
 enum { CNT_FRAME_CANDS = 0, CNT_CROP_ROIS = 1, CNT_CROP_TILES = 2, CNT_CROP_CANDS = 3,
        CNT_POOL_INTS = 4 /* 64-bit, uses 4..5 */, CNT_CROP_QUADS = 6, CNT_TICKET_F = 7, CNT_TICKET_C = 8, CNT_ERR = 9,
-       CNT_CROP_PIXELS = 10 /* 64-bit, uses 10..11 */, CNT_COUNT = 16 };
+       CNT_CROP_PIXELS = 10 /* 64-bit, uses 10..11 */, CNT_LONG_F = 12, CNT_LONG_C = 13, CNT_TICKET_LF = 14, CNT_TICKET_LC = 15,
+       CNT_MID_F = 16, CNT_MID_C = 17, CNT_TICKET_MF = 18, CNT_TICKET_MC = 19, CNT_COUNT = 24 };
 
 struct Workspace {
     // limits
@@ -41,6 +45,8 @@ struct Workspace {
     long long cap_pool_ints, cap_crop_pixels;
     // per batch geometry
     int W, H, sw, sh, ns, n_frames, n_templates;   // ns: row stride of a neighbour-mask plane = sw rounded up to 4
+    int mid_steps, long_blocks;  // tuning (env OCVAR_MID_STEPS / OCVAR_LONG_BLOCKS): tier-2 step budget, tier-3 grid
+    int dbg_follow_stop;  // experiments only (env OCVAR_DBG_FOLLOW_STOP): 1 = stop after the first follow, 2 = after the second
     int frame_strips, frame_chunks, frame_chunk_rows;  // binarise work decomposition of a frame
     // device buffers
     uint8_t* gray;          // [B][H][W]
@@ -48,6 +54,11 @@ struct Workspace {
     uint8_t* nbr_crop;      // crop pool
     StartCand* cands_frame;
     StartCand* cands_crop;
+    StartCand* mid_frame;   // starts whose border exceeded tier 1's step budget
+    StartCand* mid_crop;
+    StartCand* long_frame;  // starts whose border exceeded tier 2's step budget
+    StartCand* long_crop;
+    int cap_long;
     int* pool;              // points + DP stacks
     QuadRec* quads_frame;   // [B][MAXQ] unordered
     int* n_quads_frame;     // [B]
@@ -77,6 +88,10 @@ void launch_binarise_frames(const Workspace& ws, const uint8_t* d_bgr, int row_s
 void launch_binarise_crops(const Workspace& ws, hipStream_t stream);
 void launch_follow_frames(const Workspace& ws, hipStream_t stream);
 void launch_follow_crops(const Workspace& ws, hipStream_t stream);
+void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream);
+void launch_follow_mid_crops(const Workspace& ws, hipStream_t stream);
+void launch_follow_long_frames(const Workspace& ws, hipStream_t stream);
+void launch_follow_long_crops(const Workspace& ws, hipStream_t stream);
 void launch_order_and_crops(const Workspace& ws, hipStream_t stream);
 void launch_decode(const Workspace& ws, hipStream_t stream);
 void launch_finalise(const Workspace& ws, hipStream_t stream);

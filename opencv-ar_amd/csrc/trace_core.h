@@ -42,6 +42,7 @@ OCVAR_HD int first_cw(unsigned m, int from) {
 }
 
 enum TraceStatus { TRACE_OK = 0, TRACE_NOT_FIRST = 1, TRACE_SINGLE = 2, TRACE_OVERRUN = 3 };
+// (TRACE_OVERRUN doubles as "step budget exhausted" when the caller passes a small max_steps on purpose)
 
 struct TraceStats {
     int status;
@@ -54,7 +55,9 @@ struct TraceStats {
 // the border's first pixel is cpos-1).  nbr: neighbour masks of an sw-wide plane.  With STORE the
 // CHAIN_APPROX_SIMPLE points are written to out (x,y pairs).  Returns TRACE_NOT_FIRST as soon as a
 // scan position of this border smaller than cpos is met.
-template <bool STORE>
+// RUN: jump over straight runs with 8 mask loads in flight (pays off for a lone long border; in a wave whose
+// lanes follow different borders the extra code path only adds divergence, so the lane tiers switch it off).
+template <bool STORE, bool RUN = true>
 OCVAR_HD TraceStats trace_border(const uint8_t* nbr, int sw, int plane, int cpos, int is_hole, int* out, int max_pts,
                                  int max_steps) {
     TraceStats st;
@@ -116,20 +119,66 @@ OCVAR_HD TraceStats trace_border(const uint8_t* nbr, int sw, int plane, int cpos
             st.npts++;
             prev_s = s;
         }
-        const int i4 = i3 + dir_dy(s) * sw + dir_dx(s);
-        x += dir_dx(s);
-        y += dir_dy(s);
+        const int ddx = dir_dx(s), ddy = dir_dy(s), d = ddy * sw + ddx;
+        int i4 = i3 + d;
+        x += ddx;
+        y += ddy;
         if (i4 == i0 && i3 == i1) break;
+        if ((unsigned)i4 >= (unsigned)plane) {  // cannot happen on a consistent neighbour plane; never read outside it
+            st.status = TRACE_OVERRUN;
+            return st;
+        }
+        unsigned m4 = nbr[i4];
+        if (m4 == 0) {
+            st.status = TRACE_OVERRUN;
+            return st;
+        }
+        if (RUN && s == ((s_end + 4) & 7) && m4 == m) {
+            // Straight run.  The follower's state is (arrival direction, neighbour mask); the border went straight
+            // through i3 and i4 has the same mask, so i4 -- and every further pixel with this mask -- leaves in
+            // direction s again: no direction change (no point), same examined neighbours.  Fetch 8 pixels ahead
+            // at once (independent loads: one memory latency per 8 steps instead of one per step).
+            const bool w_ex = ((4 - (s_end + 1)) & 7) < examined, e_ex = ((0 - (s_end + 1)) & 7) < examined;
+            int p = i4;  // last pixel known to carry mask m
+            bool landed = false, closed = false;
+            while (!landed && !closed) {
+                unsigned long long ahead = 0;
+                for (int t = 1; t <= 8; t++) {
+                    int qi = p + t * d;
+                    qi = qi < 0 ? 0 : (qi >= plane ? plane - 1 : qi);
+                    ahead |= (unsigned long long)nbr[qi] << (8 * (t - 1));
+                }
+                for (int t = 1; t <= 8; t++) {
+                    // p carries mask m and leaves in direction s: its scan positions, then the step p -> q
+                    if ((w_ex && p < cpos) || (e_ex && p + 1 < cpos)) {
+                        st.status = TRACE_NOT_FIRST;
+                        return st;
+                    }
+                    const int q = p + d;
+                    x += ddx;
+                    y += ddy;
+                    if (q == i0 && p == i1) {
+                        closed = true;
+                        break;
+                    }
+                    const unsigned mq = (unsigned)(ahead >> (8 * (t - 1))) & 255u;
+                    if ((unsigned)q >= (unsigned)plane || mq == 0 || ++step >= max_steps) {
+                        st.status = TRACE_OVERRUN;
+                        return st;
+                    }
+                    p = q;
+                    if (mq != m) {
+                        m4 = mq;
+                        landed = true;
+                        break;
+                    }
+                }
+            }
+            if (closed) break;
+            i4 = p;
+        }
         i3 = i4;
-        if ((unsigned)i3 >= (unsigned)plane) {  // cannot happen on a consistent neighbour plane; never read outside it
-            st.status = TRACE_OVERRUN;
-            return st;
-        }
-        m = nbr[i3];
-        if (m == 0) {
-            st.status = TRACE_OVERRUN;
-            return st;
-        }
+        m = m4;
         s = (s + 4) & 7;
     }
     if (st.npts > 1) {

@@ -9,6 +9,11 @@
 
 using namespace ocvar;
 static int g_back = 32;
+static int g_run = 1;
+extern "C" void emul_set_run(int r) { g_run = r; }
+template <bool STORE> static TraceStats tb(const uint8_t* nbr, int sw, int plane, int cpos, int hole, int* out, int mp, int ms) {
+    return g_run ? trace_border<STORE, true>(nbr, sw, plane, cpos, hole, out, mp, ms) : trace_border<STORE, false>(nbr, sw, plane, cpos, hole, out, mp, ms);
+}
 static long long g_back_drops = 0;
 extern "C" void emul_set_back(int b) { g_back = b; }
 extern "C" long long emul_back_drops() { return g_back_drops; }
@@ -45,7 +50,7 @@ extern "C" int emul_find_contours(const uint8_t* bin, int w, int h, int* pts, in
             bool hole = !c && b(x - 1, y) && b(x, y - 1);
             if (!outer && !hole) continue;
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), w, w * h, y * w + x, 0, g_back)) { g_back_drops++; continue; }
-            TraceStats st = trace_border<true>(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, buf.data(), (int)buf.size() / 2, 4 * w * h + 16);
+            TraceStats st = tb<true>(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, buf.data(), (int)buf.size() / 2, 4 * w * h + 16);
             if (st.status == TRACE_OVERRUN) return -2;
             if (st.status == TRACE_NOT_FIRST) continue;
             C cc;
@@ -83,7 +88,7 @@ extern "C" int emul_quad_filter(const int* q, int w, int h) { return quad_filter
 
 // trace statistics (perimeter, bbox) for one start
 extern "C" int emul_trace_stats(const uint8_t* nbr, int sw, int cpos, int is_hole, double* perimeter, int* bbox, int* npts) {
-    TraceStats st = trace_border<false>(nbr, sw, 1 << 30, cpos, is_hole, nullptr, 0, 1 << 30);
+    TraceStats st = tb<false>(nbr, sw, 1 << 30, cpos, is_hole, nullptr, 0, 1 << 30);
     *perimeter = st.perimeter;
     bbox[0] = st.minx; bbox[1] = st.maxx; bbox[2] = st.miny; bbox[3] = st.maxy;
     *npts = st.npts;
@@ -114,12 +119,12 @@ extern "C" int emul_find_squares_bin(const uint8_t* bin, int sw, int sh, int img
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, 0, g_back)) { g_back_drops++; continue; }
             st_[0]++;
             // count steps by re-running with a step cap search (cheap instrumentation)
-            TraceStats st = trace_border<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, 4 * sw * sh + 16);
+            TraceStats st = tb<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, 4 * sw * sh + 16);
             if (st.status == TRACE_NOT_FIRST) {
                 int lo = 0, hi = 4 * sw * sh + 16;  // smallest cap that still reports NOT_FIRST = steps taken
                 while (lo < hi) {
                     int mid = (lo + hi) / 2;
-                    TraceStats t2 = trace_border<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, mid);
+                    TraceStats t2 = tb<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, mid);
                     if (t2.status == TRACE_NOT_FIRST) hi = mid; else lo = mid + 1;
                 }
                 st_[1] += lo + 1;
@@ -129,7 +134,7 @@ extern "C" int emul_find_squares_bin(const uint8_t* bin, int sw, int sh, int img
             if (!worth_approximating(st)) continue;
             st_[4]++;
             buf.resize(2 * (size_t)st.npts);
-            trace_border<true>(nbr.data(), sw, sw * sh, y * sw + x, hole, buf.data(), st.npts, 4 * sw * sh + 16);
+            tb<true>(nbr.data(), sw, sw * sh, y * sw + x, hole, buf.data(), st.npts, 4 * sw * sh + 16);
             std::vector<DpSlice> stack(st.npts + 2);
             int dst[2 * (DP_MAX_OUT + 1)];
             int m = approx_poly_dp(buf.data(), st.npts, st.perimeter * 0.02, dst, stack.data());
@@ -163,13 +168,13 @@ extern "C" int emul_candidate_steps(const uint8_t* bin, int sw, int sh, int* typ
             bool hole = !c && b(x - 1, y) && b(x, y - 1);
             if (!outer && !hole) continue;
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, 0, g_back)) { g_back_drops++; continue; }
-            TraceStats st = trace_border<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, 4 * sw * sh + 16);
+            TraceStats st = tb<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, 4 * sw * sh + 16);
             int s = -1;
             if (st.status == TRACE_NOT_FIRST) {
                 int lo = 0, hi = 4 * sw * sh + 16;
                 while (lo < hi) {
                     int mid = (lo + hi) / 2;
-                    TraceStats t2 = trace_border<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, mid);
+                    TraceStats t2 = tb<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, mid);
                     if (t2.status == TRACE_NOT_FIRST) hi = mid; else lo = mid + 1;
                 }
                 s = lo + 1;

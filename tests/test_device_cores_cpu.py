@@ -31,6 +31,7 @@ def same_contours(a, b):
 def test_parallel_border_starts_equal_sequential_scan(emul):
     rng = np.random.default_rng(1)
     for trial in range(300):
+        emul.emul_set_run(trial & 1)  # with and without straight-run skipping
         h, w = int(rng.integers(3, 40)), int(rng.integers(3, 40))
         dens = rng.choice([0.1, 0.3, 0.5, 0.6, 0.7, 0.9])
         b = (rng.random((h, w)) < dens).astype(np.uint8) * 255
