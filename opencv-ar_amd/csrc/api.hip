@@ -91,6 +91,7 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     if ((rc = dev_alloc(c, &w.cands_frame, (size_t)w.cap_frame_cands))) return rc;
     if ((rc = dev_alloc(c, &w.cands_crop, (size_t)w.cap_crop_cands))) return rc;
     if ((rc = dev_alloc(c, &w.pool, (size_t)w.cap_pool_ints))) return rc;
+    if ((rc = dev_alloc(c, &w.slab, (size_t)MID_BLOCKS * 256 * (4 * SLAB_PTS + 4)))) return rc;
     w.cap_long = (int)std::min<size_t>(B * 4096, (size_t)1 << 28);
     if ((rc = dev_alloc(c, &w.mid_frame, (size_t)w.cap_long))) return rc;
     if ((rc = dev_alloc(c, &w.mid_crop, (size_t)w.cap_long))) return rc;

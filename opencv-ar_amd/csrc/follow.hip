@@ -34,11 +34,19 @@ __device__ __forceinline__ PlaneRef plane_of(const Workspace& ws, int roi) {
 
 // Douglas-Peucker + quad filter on stored points, then publication of the quad (one lane).
 template <bool CROP>
+__device__ __forceinline__ void emit_quad(const Workspace& ws, const StartCand c, const int* dst);
+
+template <bool CROP>
 __device__ __forceinline__ void approximate_and_emit(const Workspace& ws, const StartCand c, const PlaneRef& pl, const int* pts,
-                                                     int npts, double perimeter, DpSlice* stack) {
+                                                     int npts, double perimeter, DpSlice* stack, bool emit = true) {
     int dst[2 * (DP_MAX_OUT + 1)];
     const int m = approx_poly_dp(pts, npts, perimeter * 0.02, dst, stack);
     if (m != 4 || !quad_filter(dst, pl.img_w, pl.img_h)) return;
+    if (emit) emit_quad<CROP>(ws, c, dst);
+}
+
+template <bool CROP>
+__device__ __forceinline__ void emit_quad(const Workspace& ws, const StartCand c, const int* dst) {
     QuadRec q;
     q.roi = c.roi;
     q.start = c.pos;
@@ -73,9 +81,17 @@ __device__ __forceinline__ bool follow_short(const Workspace& ws, const StartCan
     const PlaneRef pl = plane_of<CROP>(ws, c.roi);
     if (c.pos <= 0 || c.pos >= pl.plane) return false;
     if (TIER == 1 && !c.is_hole && earlier_start_behind(pl.nbr, pl.ns, pl.plane, c.pos, 0, BACK_STEPS)) return false;
-    const TraceStats st = trace_border<false, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
-    if (st.status == TRACE_OVERRUN) return true;  // budget exhausted: a long border
+    // tier 2 stores the points while it follows (private slab), so a border that fits needs no second follow
+    int* slab = TIER == 2 ? ws.slab + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (4 * SLAB_PTS + 4) : nullptr;
+    const TraceStats st = TIER == 2 ? trace_border<true, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, slab, SLAB_PTS, BUDGET)
+                                    : trace_border<false, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
+    if (st.status == TRACE_OVERRUN) return true;  // budget exhausted: a longer border
     if (!worth_approximating(st) || ws.dbg_follow_stop == 1) return false;
+    if (TIER == 2 && st.npts <= SLAB_PTS) {
+        if (ws.dbg_follow_stop == 3) return false;
+        approximate_and_emit<CROP>(ws, c, pl, slab, st.npts, st.perimeter, reinterpret_cast<DpSlice*>(slab + 2 * SLAB_PTS));
+        return false;
+    }
     const int need = 2 * st.npts + 2 * (st.npts + 2);
     const long long off = atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
     if (off + need > ws.cap_pool_ints) {
@@ -299,6 +315,7 @@ __device__ TraceStats trace_border_tiled(TileCache& t, int cpos, int is_hole, in
 template <bool CROP>
 __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
     __shared__ __attribute__((aligned(16))) uint8_t tiles[4][TILE * TILE];
+    __shared__ int lpts[4][4 * LDS_PTS + 4];   // per wave: points, then the approximation's stack
     const StartCand* longs = CROP ? ws.long_crop : ws.long_frame;
     int n = ws.counters[CROP ? CNT_LONG_C : CNT_LONG_F];
     if (n > ws.cap_long) n = ws.cap_long;
@@ -318,12 +335,21 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
         t.sh = pl.sh;
         t.tx0 = t.ty0 = -(1 << 28);
         const int max_steps = 4 * pl.plane + 16;
-        const TraceStats st = trace_border_tiled<false>(t, c.pos, c.is_hole, nullptr, 0, max_steps);
+        int* lp = lpts[threadIdx.x >> 6];
+        const TraceStats st = trace_border_tiled<true>(t, c.pos, c.is_hole, lp, LDS_PTS, max_steps);
         if (st.status == TRACE_OVERRUN) {
             if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TRACE_OVERRUN);
             continue;
         }
         if (!worth_approximating(st) || ws.dbg_follow_stop == 1) continue;
+        if (st.npts <= LDS_PTS) {   // the usual case: points are in LDS, no second follow
+            if (ws.dbg_follow_stop == 4) continue;
+            // all lanes run the approximation on the LDS points (same addresses: broadcast reads, identical stack
+            // writes), lane 0 publishes
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            approximate_and_emit<CROP>(ws, c, pl, lp, st.npts, st.perimeter, reinterpret_cast<DpSlice*>(lp + 2 * LDS_PTS), lane == 0);
+            continue;
+        }
         const int need = 2 * st.npts + 2 * (st.npts + 2);
         long long off = 0;
         if (lane == 0) off = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
@@ -420,10 +446,10 @@ void launch_follow_crops(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL((follow_kernel<true, 1>), dim3(1024), dim3(256), 0, stream, ws);
 }
 void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL((follow_kernel<false, 2>), dim3(1024), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL((follow_kernel<false, 2>), dim3(MID_BLOCKS), dim3(256), 0, stream, ws);
 }
 void launch_follow_mid_crops(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL((follow_kernel<true, 2>), dim3(1024), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL((follow_kernel<true, 2>), dim3(MID_BLOCKS), dim3(256), 0, stream, ws);
 }
 void launch_follow_long_frames(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_long_kernel<false>, dim3(ws.long_blocks), dim3(256), 0, stream, ws);

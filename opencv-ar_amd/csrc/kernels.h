@@ -17,6 +17,9 @@ constexpr int MARCH_STAGE = 512;           // border starts a wave stages in LDS
 constexpr int BACK_STEPS = 32;
 constexpr int SHORT_STEPS = 96;            // step budget of follower tier 1 (every plausible start, one lane each)
 constexpr int MID_STEPS = 3072;            // step budget of tier 2 (borders that outlived tier 1, one lane each); the rest: tier 3, one wave each
+constexpr int SLAB_PTS = 1024;             // points a tier-2 lane can keep in its private slab (no second follow needed below that)
+constexpr int MID_BLOCKS = 512;            // tier-2 grid (x256 threads, one slab each)
+constexpr int LDS_PTS = 512;               // points a tier-3 wave can keep in LDS
 constexpr int TILE = 64;                   // side of the LDS tile the wave-per-border follower walks in             // backward look of an outer start before it follows its border
 
 // error bits accumulated in Workspace::err[0]
@@ -60,6 +63,7 @@ struct Workspace {
     StartCand* long_crop;
     int cap_long;
     int* pool;              // points + DP stacks
+    int* slab;              // [MID_BLOCKS*256][4*SLAB_PTS+4] private point + stack space of the tier-2 lanes
     QuadRec* quads_frame;   // [B][MAXQ] unordered
     int* n_quads_frame;     // [B]
     float* squares;         // [B][MAXQ][8] ordered, after tracking

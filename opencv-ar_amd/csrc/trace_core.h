@@ -262,7 +262,8 @@ OCVAR_HD int approx_poly_dp(const int* src, int count, double parameter, int* ds
         stack[top++] = right;
         stack[top++] = slice;
     }
-    while (top > 0) {
+    for (int guard = 4 * count + 16; top > 0;) {  // every iteration emits a vertex or splits a slice: <= 2*count rounds
+        if (--guard < 0) return DP_MAX_OUT + 1;
         slice = stack[--top];
         int e = slice.end >= count ? slice.end - count : slice.end;
         int b = slice.start >= count ? slice.start - count : slice.start;
