@@ -431,5 +431,6 @@ extern "C" int ocvar_hip_counters(OcvarHip* c, long long* out, int n) {
                       (long long)*reinterpret_cast<const unsigned long long*>(h + CNT_POOL_INTS)};
     int k = 0;
     for (; k < 6 && k < n; k++) out[k] = v[k];
+    for (; k < 9 && k < n; k++) out[k] = h[20 + (k - 6)];  // instrumentation slots
     return k;
 }

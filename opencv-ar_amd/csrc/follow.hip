@@ -81,17 +81,29 @@ __device__ __forceinline__ bool follow_short(const Workspace& ws, const StartCan
     const PlaneRef pl = plane_of<CROP>(ws, c.roi);
     if (c.pos <= 0 || c.pos >= pl.plane) return false;
     if (TIER == 1 && !c.is_hole && earlier_start_behind(pl.nbr, pl.ns, pl.plane, c.pos, 0, BACK_STEPS)) return false;
-    // tier 2 stores the points while it follows (private slab), so a border that fits needs no second follow
-    int* slab = TIER == 2 ? ws.slab + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (4 * SLAB_PTS + 4) : nullptr;
-    const TraceStats st = TIER == 2 ? trace_border<true, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, slab, SLAB_PTS, BUDGET)
-                                    : trace_border<false, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
-    if (st.status == TRACE_OVERRUN) return true;  // budget exhausted: a longer border
-    if (!worth_approximating(st) || ws.dbg_follow_stop == 1) return false;
-    if (TIER == 2 && st.npts <= SLAB_PTS) {
-        if (ws.dbg_follow_stop == 3) return false;
-        approximate_and_emit<CROP>(ws, c, pl, slab, st.npts, st.perimeter, reinterpret_cast<DpSlice*>(slab + 2 * SLAB_PTS));
-        return false;
+    if (TIER == 2) {
+        // tier 2 stores the points while it follows (lean loop, private slab): a border that fits needs no second
+        // follow, and its statistics come from the stored points
+        int* slab = ws.slab + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (4 * SLAB_PTS + 4);
+        const LeanTrace lt = trace_lean(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, slab, SLAB_PTS, BUDGET);
+        if (lt.status == TRACE_OVERRUN) return true;  // budget exhausted: a longer border
+        if (ws.dbg_follow_stop == 9) {  // instrumentation: longest / total border length seen by tier 2
+            atomicMax(ws.counters + 20, lt.steps);
+            atomicAdd(ws.counters + 21, lt.steps);
+            atomicAdd(ws.counters + 22, 1);
+        }
+        if (lt.status != TRACE_OK || lt.npts < 4) return false;
+        if (lt.npts <= SLAB_PTS) {
+            const TraceStats sp = stats_of_points(slab, lt.npts);
+            if (!worth_approximating(sp) || ws.dbg_follow_stop == 1 || ws.dbg_follow_stop == 3) return false;
+            approximate_and_emit<CROP>(ws, c, pl, slab, sp.npts, sp.perimeter, reinterpret_cast<DpSlice*>(slab + 2 * SLAB_PTS));
+            return false;
+        }
     }
+    // tier 1, and tier-2 borders with more points than a slab holds: statistics first, then a storing follow
+    const TraceStats st = trace_border<false, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
+    if (st.status == TRACE_OVERRUN) return true;
+    if (!worth_approximating(st) || ws.dbg_follow_stop == 1) return false;
     const int need = 2 * st.npts + 2 * (st.npts + 2);
     const long long off = atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
     if (off + need > ws.cap_pool_ints) {
@@ -178,138 +190,130 @@ __device__ __forceinline__ unsigned tile_get(TileCache& t, int x, int y) {
     return t.lds[(y - t.ty0) * TILE + (x - t.tx0)];
 }
 
-template <bool STORE>
-__device__ TraceStats trace_border_tiled(TileCache& t, int cpos, int is_hole, int* out, int max_pts, int max_steps) {
+// Lean follower on the tile cache (wave-uniform: all lanes walk the same border).  Points go to `out` (LDS or
+// global, written by lane 0) up to max_pts; statistics are recomputed from the points afterwards.
+__device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* out, int max_pts, int max_steps) {
     const int lane = threadIdx.x & 63;
-    TraceStats st;
-    st.status = TRACE_OK;
-    st.npts = 0;
-    st.minx = st.miny = 0x7fffffff;
-    st.maxx = st.maxy = -0x7fffffff;
-    st.perimeter = 0.0;
+    LeanTrace r;
+    r.status = TRACE_OK;
+    r.npts = 0;
+    r.steps = 0;
     const int ns = t.ns;
     const int i0 = cpos - is_hole;
     const int x0 = i0 % ns, y0 = i0 / ns;
     int x = x0, y = y0;
     unsigned m = tile_get(t, x, y);
     if (m == 0) {
-        st.status = TRACE_SINGLE;
-        st.npts = 1;
-        return st;
+        r.status = TRACE_SINGLE;
+        r.npts = 1;
+        return r;
     }
     int s = first_cw(m, (is_hole ? 0 : 4) - 1);
-    const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
+    const int x1 = x0 + step_dx(s), y1 = y0 + step_dy(s);
     int prev_s = s ^ 4;
-    int fx = 0, fy = 0, lx = 0, ly = 0;
-    for (int step = 0;; step++) {
+    int straight = 0;  // consecutive straight steps through identical masks (a long run is likely once this is 2)
+    int step = 0;
+    for (;; step++) {
         if (step >= max_steps) {
-            st.status = TRACE_OVERRUN;
-            return st;
+            r.status = TRACE_OVERRUN;
+            break;
         }
-        const int s_end = s;
-        s = first_ccw(m, s_end + 1);
-        const int examined = (s - (s_end + 1)) & 7;
-        const int i3 = y * ns + x;
-        if ((((4 - (s_end + 1)) & 7) < examined && i3 < cpos) || (((0 - (s_end + 1)) & 7) < examined && i3 + 1 < cpos)) {
-            st.status = TRACE_NOT_FIRST;
-            return st;
+        const int from = (s + 1) & 7;
+        const int tz = __builtin_ctz(((m * 0x101u) >> from) & 0xffu);
+        const int e = (from + tz) & 7;
+        const unsigned passed = ((((1u << tz) - 1u) * 0x101u) << from) >> 8;
+        const int idx = y * ns + x;
+        if (((passed & 0x10u) && idx < cpos) || ((passed & 1u) && idx + 1 < cpos)) {
+            r.status = TRACE_NOT_FIRST;
+            break;
         }
-        if (s != prev_s) {
-            if (st.npts == 0) {
-                fx = x;
-                fy = y;
-            } else {
-                const float dx = (float)x - (float)lx, dy = (float)y - (float)ly;
-                st.perimeter += (double)sqrt_rn(dx * dx + dy * dy);
+        if (e != prev_s) {
+            if (r.npts < max_pts && lane == 0) {
+                out[2 * r.npts] = x;
+                out[2 * r.npts + 1] = y;
             }
-            lx = x;
-            ly = y;
-            st.minx = x < st.minx ? x : st.minx;
-            st.maxx = x > st.maxx ? x : st.maxx;
-            st.miny = y < st.miny ? y : st.miny;
-            st.maxy = y > st.maxy ? y : st.maxy;
-            if (STORE && st.npts < max_pts && lane == 0) {
-                out[2 * st.npts] = x;
-                out[2 * st.npts + 1] = y;
-            }
-            st.npts++;
-            prev_s = s;
+            r.npts++;
+            prev_s = e;
         }
+        const int ddx = step_dx(e), ddy = step_dy(e);
         const int px = x, py = y;
-        const int ddx = dir_dx(s), ddy = dir_dy(s);
         x += ddx;
         y += ddy;
         if (x == x0 && y == y0 && px == x1 && py == y1) break;
         if ((unsigned)x >= (unsigned)ns || (unsigned)y >= (unsigned)t.sh) {
-            st.status = TRACE_OVERRUN;
-            return st;
+            r.status = TRACE_OVERRUN;
+            break;
         }
         unsigned m4 = tile_get(t, x, y);
         if (m4 == 0) {
-            st.status = TRACE_OVERRUN;
-            return st;
+            r.status = TRACE_OVERRUN;
+            break;
         }
-        if (s == ((s_end + 4) & 7) && m4 == m) {
-            // Straight run (see trace_core.h): every further pixel with this mask leaves in direction s again.  The 64
-            // lanes look at the next 64 pixels of the line at once; the first lane that sees another mask, the end of
-            // the window, or the closing step decides how far the walk jumps.
-            const bool w_ex = ((4 - (s_end + 1)) & 7) < examined, e_ex = ((0 - (s_end + 1)) & 7) < examined;
-            bool closed = false;
-            for (;;) {
-                const int qx = x + (lane + 1) * ddx, qy = y + (lane + 1) * ddy;
-                const bool in_tile = (unsigned)(qx - t.tx0) < (unsigned)TILE && (unsigned)(qy - t.ty0) < (unsigned)TILE;
-                const unsigned mq = in_tile ? t.lds[(qy - t.ty0) * TILE + (qx - t.tx0)] : 256u;
-                const bool closes = qx == x0 && qy == y0 && qx - ddx == x1 && qy - ddy == y1;
-                const unsigned long long stop = __ballot(closes || mq != m);
-                const int k = stop ? __ffsll((long long)stop) - 1 : 64;   // pixels (x,y)+1..k carry mask m
-                // scan positions of the pixels passed: monotonic along a line, so the two ends decide
-                const int pa = y * ns + x, pb = (y + k * ddy) * ns + x + k * ddx;
-                if ((w_ex && (pa < cpos || pb < cpos)) || (e_ex && (pa + 1 < cpos || pb + 1 < cpos))) {
-                    st.status = TRACE_NOT_FIRST;
-                    return st;
-                }
-                x += k * ddx;
-                y += k * ddy;
-                step += k;
-                if (step >= max_steps) {
-                    st.status = TRACE_OVERRUN;
-                    return st;
-                }
-                if (k == 64) continue;
-                const int stop_closes = __shfl((int)closes, k);
-                const unsigned stop_m = (unsigned)__shfl((int)mq, k);
-                if (stop_closes) {
-                    closed = true;
+        if (e == (s ^ 4) && m4 == m) {
+            // straight through a pixel whose successor has the same mask: the state repeats (trace_core.h)
+            if (++straight >= 2) {
+                // a run: the 64 lanes inspect the next 64 pixels of the line at once; the first lane that sees another
+                // mask, the end of the window or the closing step decides how far the walk jumps
+                bool closed = false, bad = false;
+                for (;;) {
+                    const int qx = x + (lane + 1) * ddx, qy = y + (lane + 1) * ddy;
+                    const bool in_tile = (unsigned)(qx - t.tx0) < (unsigned)TILE && (unsigned)(qy - t.ty0) < (unsigned)TILE;
+                    const unsigned mq = in_tile ? t.lds[(qy - t.ty0) * TILE + (qx - t.tx0)] : 256u;
+                    const bool closes = qx == x0 && qy == y0 && qx - ddx == x1 && qy - ddy == y1;
+                    const unsigned long long stop = __ballot(closes || mq != m);
+                    const int k = stop ? __ffsll((long long)stop) - 1 : 64;   // pixels (x,y)+1..k carry mask m
+                    // scan positions are monotonic along a line: the two ends decide
+                    const int pa = y * ns + x, pb = (y + k * ddy) * ns + x + k * ddx;
+                    if (((passed & 0x10u) && (pa < cpos || pb < cpos)) || ((passed & 1u) && (pa + 1 < cpos || pb + 1 < cpos))) {
+                        r.status = TRACE_NOT_FIRST;
+                        bad = true;
+                        break;
+                    }
+                    x += k * ddx;
+                    y += k * ddy;
+                    step += k;
+                    if (step >= max_steps) {
+                        r.status = TRACE_OVERRUN;
+                        bad = true;
+                        break;
+                    }
+                    if (k == 64) continue;
+                    const int stop_closes = __shfl((int)closes, k);
+                    const unsigned stop_m = (unsigned)__shfl((int)mq, k);
+                    if (stop_closes) {
+                        closed = true;
+                        break;
+                    }
+                    if (stop_m == 256u) {  // end of the window: re-centre ahead and keep running
+                        if ((unsigned)(x + ddx) >= (unsigned)ns || (unsigned)(y + ddy) >= (unsigned)t.sh) {
+                            r.status = TRACE_OVERRUN;
+                            bad = true;
+                            break;
+                        }
+                        tile_load(t, x + ddx, y + ddy, ddx, ddy);
+                        continue;
+                    }
+                    x += ddx;   // land on the first pixel with a different mask
+                    y += ddy;
+                    step++;
+                    m4 = stop_m;
                     break;
                 }
-                if (stop_m == 256u) {  // end of the window: re-centre ahead and keep running
-                    if ((unsigned)(x + ddx) >= (unsigned)ns || (unsigned)(y + ddy) >= (unsigned)t.sh) {
-                        st.status = TRACE_OVERRUN;
-                        return st;
-                    }
-                    tile_load(t, x + ddx, y + ddy, ddx, ddy);
-                    continue;
+                if (bad || closed) break;
+                if (m4 == 0) {
+                    r.status = TRACE_OVERRUN;
+                    break;
                 }
-                x += ddx;   // land on the first pixel with a different mask
-                y += ddy;
-                step++;
-                m4 = stop_m;
-                break;
+                straight = 0;
             }
-            if (closed) break;
-            if (m4 == 0) {
-                st.status = TRACE_OVERRUN;
-                return st;
-            }
+        } else {
+            straight = 0;
         }
         m = m4;
-        s = (s + 4) & 7;
+        s = e ^ 4;
     }
-    if (st.npts > 1) {
-        const float dx = (float)fx - (float)lx, dy = (float)fy - (float)ly;
-        st.perimeter += (double)sqrt_rn(dx * dx + dy * dy);
-    }
-    return st;
+    r.steps = step;
+    return r;
 }
 
 template <bool CROP>
@@ -336,20 +340,25 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
         t.tx0 = t.ty0 = -(1 << 28);
         const int max_steps = 4 * pl.plane + 16;
         int* lp = lpts[threadIdx.x >> 6];
-        const TraceStats st = trace_border_tiled<true>(t, c.pos, c.is_hole, lp, LDS_PTS, max_steps);
-        if (st.status == TRACE_OVERRUN) {
+        const LeanTrace lt = trace_lean_tiled(t, c.pos, c.is_hole, lp, LDS_PTS, max_steps);
+        if (lt.status == TRACE_OVERRUN) {
             if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TRACE_OVERRUN);
             continue;
         }
-        if (!worth_approximating(st) || ws.dbg_follow_stop == 1) continue;
-        if (st.npts <= LDS_PTS) {   // the usual case: points are in LDS, no second follow
+        if (lt.status != TRACE_OK || lt.npts < 4 || ws.dbg_follow_stop == 1) continue;
+        if (lt.npts <= LDS_PTS) {   // the usual case: points are in LDS, no second follow
             if (ws.dbg_follow_stop == 4) continue;
-            // all lanes run the approximation on the LDS points (same addresses: broadcast reads, identical stack
-            // writes), lane 0 publishes
+            // all lanes run statistics + approximation on the LDS points (same addresses: broadcast reads, identical
+            // stack writes), lane 0 publishes
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            approximate_and_emit<CROP>(ws, c, pl, lp, st.npts, st.perimeter, reinterpret_cast<DpSlice*>(lp + 2 * LDS_PTS), lane == 0);
+            const TraceStats sp = stats_of_points(lp, lt.npts);
+            if (!worth_approximating(sp)) continue;
+            approximate_and_emit<CROP>(ws, c, pl, lp, sp.npts, sp.perimeter, reinterpret_cast<DpSlice*>(lp + 2 * LDS_PTS), lane == 0);
             continue;
         }
+        // more points than the LDS buffer holds: store them in the pool with a second follow
+        TraceStats st;
+        st.npts = lt.npts;
         const int need = 2 * st.npts + 2 * (st.npts + 2);
         long long off = 0;
         if (lane == 0) off = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
@@ -359,11 +368,13 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
             continue;
         }
         int* pts = ws.pool + off;
-        trace_border_tiled<true>(t, c.pos, c.is_hole, pts, st.npts, max_steps);
+        trace_lean_tiled(t, c.pos, c.is_hole, pts, st.npts, max_steps);
         if (ws.dbg_follow_stop == 2) continue;
         if (lane == 0) {
             __threadfence_block();
-            approximate_and_emit<CROP>(ws, c, pl, pts, st.npts, st.perimeter, reinterpret_cast<DpSlice*>(pts + 2 * st.npts));
+            const TraceStats sp = stats_of_points(pts, st.npts);
+            if (worth_approximating(sp))
+                approximate_and_emit<CROP>(ws, c, pl, pts, sp.npts, sp.perimeter, reinterpret_cast<DpSlice*>(pts + 2 * st.npts));
         }
     }
 }

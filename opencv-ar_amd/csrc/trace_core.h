@@ -49,6 +49,7 @@ struct TraceStats {
     int npts;
     int minx, maxx, miny, maxy;
     double perimeter;  // cvArcLength(closed): float32 segment lengths summed in double
+    int steps;         // pixels visited (instrumentation)
 };
 
 // Follows the border that cvFindContours would start at scan position cpos (is_hole: 1->0 transition,
@@ -66,6 +67,7 @@ OCVAR_HD TraceStats trace_border(const uint8_t* nbr, int sw, int plane, int cpos
     st.minx = st.miny = 0x7fffffff;
     st.maxx = st.maxy = -0x7fffffff;
     st.perimeter = 0.0;
+    st.steps = 0;
     const int i0 = cpos - is_hole;
     int x = i0 % sw, y = i0 / sw;
     unsigned m = nbr[i0];
@@ -85,7 +87,8 @@ OCVAR_HD TraceStats trace_border(const uint8_t* nbr, int sw, int plane, int cpos
     int i3 = i0;
     int prev_s = s ^ 4;
     int fx = 0, fy = 0, lx = 0, ly = 0;
-    for (int step = 0;; step++) {
+    int step = 0;
+    for (;; step++) {
         if (step >= max_steps) {
             st.status = TRACE_OVERRUN;
             return st;
@@ -184,6 +187,106 @@ OCVAR_HD TraceStats trace_border(const uint8_t* nbr, int sw, int plane, int cpos
     if (st.npts > 1) {
         float dx = (float)fx - (float)lx, dy = (float)fy - (float)ly;
         st.perimeter += (double)sqrt_rn(dx * dx + dy * dy);
+    }
+    st.steps = step;
+    return st;
+}
+
+// ---- lean follower -------------------------------------------------------------------------------------------
+// Same stepping rules as trace_border, stripped to the dependent chain: no statistics while walking (they are
+// recomputed from the stored points afterwards), direction deltas from packed 2-bit tables, the examined-neighbour
+// test as one rotated bit mask.  Stores up to max_pts points; npts keeps counting beyond that.
+struct LeanTrace {
+    int status;
+    int npts;
+    int steps;
+};
+
+OCVAR_HD int step_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }   // 1,1,0,-1,-1,-1,0,1
+OCVAR_HD int step_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }   // 0,-1,-1,-1,0,1,1,1
+
+OCVAR_HD LeanTrace trace_lean(const uint8_t* nbr, int ns, int plane, int cpos, int is_hole, int* out, int max_pts, int max_steps) {
+    LeanTrace r;
+    r.status = TRACE_OK;
+    r.npts = 0;
+    r.steps = 0;
+    const int i0 = cpos - is_hole;
+    int x = i0 % ns, y = i0 / ns;
+    unsigned m = nbr[i0];
+    if (m == 0) {
+        r.status = TRACE_SINGLE;
+        r.npts = 1;
+        return r;
+    }
+    int s = first_cw(m, (is_hole ? 0 : 4) - 1);       // direction of the border's last pixel seen from its first
+    const int i1 = i0 + step_dy(s) * ns + step_dx(s);
+    int idx = i0;
+    int prev_s = s ^ 4;
+    int step = 0;
+    for (;; step++) {
+        if (step >= max_steps) {
+            r.status = TRACE_OVERRUN;
+            break;
+        }
+        const int from = (s + 1) & 7;
+        const int t = __builtin_ctz(((m * 0x101u) >> from) & 0xffu);   // zero neighbours passed before the next border pixel
+        const int e = (from + t) & 7;                                   // exit direction
+        const unsigned passed = ((((1u << t) - 1u) * 0x101u) << from) >> 8;   // 8-bit rotate of t ones to position `from`
+        if (((passed & 0x10u) && idx < cpos) || ((passed & 1u) && idx + 1 < cpos)) {
+            r.status = TRACE_NOT_FIRST;
+            break;
+        }
+        if (e != prev_s) {
+            if (r.npts < max_pts) {
+                out[2 * r.npts] = x;
+                out[2 * r.npts + 1] = y;
+            }
+            r.npts++;
+            prev_s = e;
+        }
+        const int dx = step_dx(e), dy = step_dy(e);
+        const int nidx = idx + dy * ns + dx;
+        x += dx;
+        y += dy;
+        if (nidx == i0 && idx == i1) break;
+        if ((unsigned)nidx >= (unsigned)plane) {
+            r.status = TRACE_OVERRUN;
+            break;
+        }
+        idx = nidx;
+        m = nbr[idx];
+        if (m == 0) {
+            r.status = TRACE_OVERRUN;
+            break;
+        }
+        s = e ^ 4;
+    }
+    r.steps = step;
+    return r;
+}
+
+// cvArcLength(closed) and the bounding box of stored contour points -> the TraceStats the filters expect
+OCVAR_HD TraceStats stats_of_points(const int* pts, int n) {
+    TraceStats st;
+    st.status = TRACE_OK;
+    st.npts = n;
+    st.steps = 0;
+    st.minx = st.miny = 0x7fffffff;
+    st.maxx = st.maxy = -0x7fffffff;
+    st.perimeter = 0.0;
+    int px = pts[2 * (n - 1)], py = pts[2 * (n - 1) + 1];
+    for (int i = 0; i < n; i++) {
+        const int x = pts[2 * i], y = pts[2 * i + 1];
+        st.minx = x < st.minx ? x : st.minx;
+        st.maxx = x > st.maxx ? x : st.maxx;
+        st.miny = y < st.miny ? y : st.miny;
+        st.maxy = y > st.maxy ? y : st.maxy;
+        if (n > 1) {
+            const float dx = (float)x - (float)px, dy = (float)y - (float)py;
+            st.perimeter += (double)sqrt_rn(dx * dx + dy * dy);
+        }
+        px = x;
+        py = y;
     }
     return st;
 }

@@ -10,6 +10,8 @@
 using namespace ocvar;
 static int g_back = 32;
 static int g_run = 1;
+static int g_lean = 0;
+extern "C" void emul_set_lean(int v) { g_lean = v; }
 extern "C" void emul_set_run(int r) { g_run = r; }
 template <bool STORE> static TraceStats tb(const uint8_t* nbr, int sw, int plane, int cpos, int hole, int* out, int mp, int ms) {
     return g_run ? trace_border<STORE, true>(nbr, sw, plane, cpos, hole, out, mp, ms) : trace_border<STORE, false>(nbr, sw, plane, cpos, hole, out, mp, ms);
@@ -50,7 +52,15 @@ extern "C" int emul_find_contours(const uint8_t* bin, int w, int h, int* pts, in
             bool hole = !c && b(x - 1, y) && b(x, y - 1);
             if (!outer && !hole) continue;
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), w, w * h, y * w + x, 0, g_back)) { g_back_drops++; continue; }
-            TraceStats st = tb<true>(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, buf.data(), (int)buf.size() / 2, 4 * w * h + 16);
+            TraceStats st;
+            if (g_lean) {
+                LeanTrace lt = trace_lean(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, buf.data(), (int)buf.size() / 2, 4 * w * h + 16);
+                st.status = lt.status;
+                st.npts = lt.npts;
+                if (lt.status == TRACE_SINGLE) { buf[0] = x; buf[1] = y; }
+            } else {
+                st = tb<true>(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, buf.data(), (int)buf.size() / 2, 4 * w * h + 16);
+            }
             if (st.status == TRACE_OVERRUN) return -2;
             if (st.status == TRACE_NOT_FIRST) continue;
             C cc;
@@ -118,6 +128,26 @@ extern "C" int emul_find_squares_bin(const uint8_t* bin, int sw, int sh, int img
             if (!outer && !hole) continue;
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, 0, g_back)) { g_back_drops++; continue; }
             st_[0]++;
+            if (g_lean) {   // the tier-2/3 flow: store while following, statistics from the stored points
+                buf.resize(2 * 4096);
+                LeanTrace lt = trace_lean(nbr.data(), sw, sw * sh, y * sw + x, hole, buf.data(), 4096, 4 * sw * sh + 16);
+                if (lt.status == TRACE_OVERRUN || lt.npts > 4096) return -3;
+                if (lt.status != TRACE_OK) continue;
+                st_[3]++;
+                TraceStats st = stats_of_points(buf.data(), lt.npts);
+                if (!worth_approximating(st)) continue;
+                st_[4]++;
+                std::vector<DpSlice> stack(st.npts + 2);
+                int dst[2 * (DP_MAX_OUT + 1)];
+                int m = approx_poly_dp(buf.data(), st.npts, st.perimeter * 0.02, dst, stack.data());
+                if (m == 4 && quad_filter(dst, img_w, img_h)) {
+                    Q q;
+                    q.start = y * sw + x;
+                    memcpy(q.p, dst, sizeof q.p);
+                    out.push_back(q);
+                }
+                continue;
+            }
             // count steps by re-running with a step cap search (cheap instrumentation)
             TraceStats st = tb<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, 4 * sw * sh + 16);
             if (st.status == TRACE_NOT_FIRST) {
