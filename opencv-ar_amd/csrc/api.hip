@@ -83,10 +83,10 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     w.cap_crop_tiles = (int)std::min<size_t>(B * 4096, (size_t)1 << 30);
     w.cap_crop_quads = (int)(B * MAXQ * 4);
     w.cap_pool_ints = (long long)B * (1 << 20);
-    w.cap_crop_pixels = (long long)(2 * B * (size_t)(max_width + 16) * max_height);
+    w.cap_crop_pixels = (long long)(2 * B * (size_t)(max_width + 16) * (max_height + 8));
     int rc;
     if ((rc = dev_alloc(c, &w.gray, B * WH))) return rc;
-    if ((rc = dev_alloc(c, &w.nbr_frame, B * (size_t)(max_width + 16) * max_height))) return rc;
+    if ((rc = dev_alloc(c, &w.nbr_frame, B * (size_t)(max_width + 16) * (max_height + 8)))) return rc;
     if ((rc = dev_alloc(c, &w.nbr_crop, (size_t)w.cap_crop_pixels))) return rc;
     if ((rc = dev_alloc(c, &w.cands_frame, (size_t)w.cap_frame_cands))) return rc;
     if ((rc = dev_alloc(c, &w.cands_crop, (size_t)w.cap_crop_cands))) return rc;
@@ -116,6 +116,8 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     if ((rc = dev_alloc(c, &w.templates, (size_t)MAXT))) return rc;
     if ((rc = dev_alloc(c, &w.camera, (size_t)1))) return rc;
     if ((rc = dev_alloc(c, &w.counters, (size_t)CNT_COUNT))) return rc;
+    if ((rc = dev_alloc(c, &w.dbg, (size_t)8192 * 4))) return rc;
+    HIP_TRY(c, hipMemset(w.dbg, 0, 8192 * 4 * sizeof(long long)));
     w.crop_pixels = reinterpret_cast<unsigned long long*>(w.counters + CNT_CROP_PIXELS);
     HIP_TRY(c, hipMemset(w.n_prev, 0, B * sizeof(int)));
     HIP_TRY(c, hipMemset(w.counters, 0, CNT_COUNT * sizeof(int)));
@@ -361,11 +363,12 @@ extern "C" int ocvar_hip_debug_binary(OcvarHip* c, int frame, uint8_t* h) {
     if (!c || !h || frame < 0 || frame >= c->ws.n_frames) return OCVAR_E_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     const int sw = c->ws.sw, sh = c->ws.sh, ns = c->ws.ns;
-    std::vector<uint8_t> nbr((size_t)ns * sh);
-    HIP_TRY(c, hipMemcpy(nbr.data(), c->ws.nbr_frame + (size_t)frame * ns * sh, nbr.size(), hipMemcpyDeviceToHost));
+    const size_t bytes = (size_t)nbr_plane_bytes(ns, sh);
+    std::vector<uint8_t> nbr(bytes);
+    HIP_TRY(c, hipMemcpy(nbr.data(), c->ws.nbr_frame + (size_t)frame * bytes, bytes, hipMemcpyDeviceToHost));
     // pixel (x,y) is the west neighbour (bit 4) of (x+1,y); the 1-px frame is zero as cvFindContours makes it
     for (int y = 0; y < sh; y++)
-        for (int x = 0; x < sw; x++) h[(size_t)y * sw + x] = (x + 1 < sw && ((nbr[(size_t)y * ns + x + 1] >> 4) & 1)) ? 255 : 0;
+        for (int x = 0; x < sw; x++) h[(size_t)y * sw + x] = (x + 1 < sw && ((nbr[(size_t)nbr_addr(x + 1, y, ns)] >> 4) & 1)) ? 255 : 0;
     return OCVAR_OK;
 }
 
@@ -421,6 +424,12 @@ extern "C" int ocvar_hip_stage_ms(OcvarHip* c, float* ms, int n) {
         k = 8;
     }
     return k;
+}
+
+extern "C" int ocvar_hip_debug_waves(OcvarHip* c, long long* out /* 8192*4 */) {
+    if (!c || !out) return OCVAR_E_ARG;
+    HIP_TRY(c, hipMemcpy(out, c->ws.dbg, 8192 * 4 * sizeof(long long), hipMemcpyDeviceToHost));
+    return OCVAR_OK;
 }
 
 extern "C" int ocvar_hip_counters(OcvarHip* c, long long* out, int n) {

@@ -285,7 +285,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                     const unsigned e2 = lut[((A >> 2) & 7u) | (((M >> 2) & 7u) << 3) | (((Bw >> 2) & 7u) << 6)];
                     const unsigned e3 = lut[((A >> 3) & 7u) | (((M >> 3) & 7u) << 3) | (((Bw >> 3) & 7u) << 6)];
                     if (out_lane)
-                        *reinterpret_cast<unsigned*>(o.nbr + (long long)yr * o.ns + c0) =
+                        *reinterpret_cast<unsigned*>(o.nbr + nbr_addr(c0, yr, o.ns)) =
                             (e0 & 255u) | ((e1 & 255u) << 8) | ((e2 & 255u) << 16) | ((e3 & 255u) << 24);
                     // plausible border starts (sparse): types of the lane's 4 pixels, 2 bits each
                     unsigned types = 0;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void binarise_frames_kernel(Workspace ws, cons
     MarchOut o;
     o.gray = ws.gray + (size_t)f * ws.W * ws.H;
     o.gray_stride = ws.W;
-    o.nbr = ws.nbr_frame + (size_t)f * ws.ns * ws.sh;
+    o.nbr = ws.nbr_frame + (size_t)f * nbr_plane_bytes(ws.ns, ws.sh);
     o.ns = ws.ns;
     o.roi = f;
     o.cands = ws.cands_frame;

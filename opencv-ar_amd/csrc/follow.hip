@@ -26,7 +26,7 @@ __device__ __forceinline__ PlaneRef plane_of(const Workspace& ws, int roi) {
         p.nbr = ws.nbr_crop + r.nbr_off;
     } else {
         p.ns = ws.ns; p.sh = ws.sh; p.img_w = ws.W; p.img_h = ws.H;
-        p.nbr = ws.nbr_frame + (size_t)roi * ws.ns * ws.sh;
+        p.nbr = ws.nbr_frame + (size_t)roi * nbr_plane_bytes(ws.ns, ws.sh);
     }
     p.plane = p.ns * p.sh;
     return p;
@@ -70,13 +70,210 @@ __device__ __forceinline__ void emit_quad(const Workspace& ws, const StartCand c
     }
 }
 
+// ---- wave-cooperative statistics + polygon approximation ------------------------------------------------------
+// One border at a time, all 64 lanes on its stored points: the scans of cvApproxPoly (farthest point from the
+// start, farthest point from a chord) are strided over the lanes with coalesced loads and finished by a wave
+// max-reduction; the slice stack and the handful of output vertices are wave-uniform.  Results are bit-identical
+// to trace_core.h::approx_poly_dp / stats_of_points ("first maximum wins" = largest value, then smallest index;
+// the perimeter is a sum of float32 values small enough that every partial sum is exact in double, so the
+// summation order does not matter).
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long b = __double_as_longlong(v);
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)b, off), hi = (unsigned)__shfl_xor((int)(unsigned)((unsigned long long)b >> 32), off);
+        v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    return v;
+}
+
+__device__ TraceStats wave_stats_of_points(const int* pts, int n) {
+    const int lane = threadIdx.x & 63;
+    int minx = 0x7fffffff, miny = 0x7fffffff, maxx = -0x7fffffff, maxy = -0x7fffffff;
+    double per = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const int x = pts[2 * i], y = pts[2 * i + 1];
+        const int p = i == 0 ? n - 1 : i - 1;
+        const int px = pts[2 * p], py = pts[2 * p + 1];
+        minx = x < minx ? x : minx; maxx = x > maxx ? x : maxx;
+        miny = y < miny ? y : miny; maxy = y > maxy ? y : maxy;
+        if (n > 1) {
+            const float dx = (float)x - (float)px, dy = (float)y - (float)py;
+            per += (double)sqrt_rn(dx * dx + dy * dy);
+        }
+    }
+    TraceStats st;
+    st.status = TRACE_OK;
+    st.npts = n;
+    st.steps = 0;
+    st.minx = wave_min_i32(minx); st.maxx = wave_max_i32(maxx);
+    st.miny = wave_min_i32(miny); st.maxy = wave_max_i32(maxy);
+    st.perimeter = wave_sum_f64(per);
+    return st;
+}
+
+constexpr int WAVE_STACK = 96;   // slices of the cooperative approximation's LDS stack
+
+// returns the vertex count (DP_MAX_OUT+1 = "more than 4 after clean-up"), or -1 if the LDS stack would overflow
+__device__ int wave_approx_poly_dp(const int* src, int count, double parameter, int* dst, DpSlice* stack /* LDS, WAVE_STACK */) {
+    const int lane = threadIdx.x & 63;
+    float eps = (float)parameter;
+    eps *= eps;
+    int top = 0, new_count = 0;
+    DpSlice slice = {0, 0}, right = {0, 0};
+    int sx = 0, sy = 0;
+    bool le_eps = false;
+    int pos = 0;
+    for (int it = 0; it < 3; it++) {
+        pos = (pos + right.start) % count;
+        sx = src[2 * pos];
+        sy = src[2 * pos + 1];
+        unsigned long long best = 0;
+        for (int j = 1 + lane; j < count; j += 64) {
+            int q = pos + j;
+            q = q >= count ? q - count : q;
+            const int dx = src[2 * q] - sx, dy = src[2 * q + 1] - sy;
+            const unsigned dist = (unsigned)(dx * dx + dy * dy);
+            const unsigned long long key = dist ? ((unsigned long long)dist << 32) | (unsigned)~(unsigned)j : 0ull;
+            best = key > best ? key : best;
+        }
+        best = wave_max_u64(best);
+        const int max_dist = (int)(best >> 32);
+        if (best) right.start = (int)~(unsigned)best;
+        le_eps = (float)max_dist <= eps;
+    }
+    if (le_eps) {
+        dst[0] = sx;
+        dst[1] = sy;
+        new_count = 1;
+    } else {
+        slice.start = pos;
+        slice.end = right.start += slice.start;
+        right.start -= right.start >= count ? count : 0;
+        right.end = slice.start;
+        if (right.end < right.start) right.end += count;
+        if (lane == 0) {
+            stack[0] = right;
+            stack[1] = slice;
+        }
+        top = 2;
+    }
+    for (int guard = 4 * count + 16; top > 0;) {
+        if (--guard < 0) return DP_MAX_OUT + 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        slice = stack[--top];
+        const int e = slice.end >= count ? slice.end - count : slice.end;
+        const int b = slice.start >= count ? slice.start - count : slice.start;
+        const int ex = src[2 * e], ey = src[2 * e + 1];
+        sx = src[2 * b];
+        sy = src[2 * b + 1];
+        if (slice.end > slice.start + 1) {
+            const int dx = ex - sx, dy = ey - sy;
+            unsigned long long best = 0;
+            for (int i = slice.start + 1 + lane; i < slice.end; i += 64) {
+                const int q = i >= count ? i - count : i;
+                int d = (src[2 * q + 1] - sy) * dx - (src[2 * q] - sx) * dy;
+                d = d < 0 ? -d : d;
+                const unsigned long long key = d ? ((unsigned long long)(unsigned)d << 32) | (unsigned)~(unsigned)i : 0ull;
+                best = key > best ? key : best;
+            }
+            best = wave_max_u64(best);
+            const int max_dist = (int)(best >> 32);
+            if (best) right.start = (int)~(unsigned)best;
+            le_eps = (double)max_dist * max_dist <= (double)eps * ((double)dx * dx + (double)dy * dy);
+        } else {
+            le_eps = true;
+        }
+        if (le_eps) {
+            if (new_count >= DP_MAX_OUT) return DP_MAX_OUT + 1;
+            dst[2 * new_count] = sx;
+            dst[2 * new_count + 1] = sy;
+            new_count++;
+        } else {
+            right.end = slice.end;
+            slice.end = right.start;
+            if (top + 2 > WAVE_STACK) return -1;
+            if (lane == 0) {
+                stack[top] = right;
+                stack[top + 1] = slice;
+            }
+            top += 2;
+        }
+    }
+    // clean-up of nearly collinear vertices on the closed ring (wave-uniform, <= 8 vertices)
+    const int n = new_count;
+    int r = n - 1;
+    sx = dst[2 * r];
+    sy = dst[2 * r + 1];
+    if (++r >= n) r = 0;
+    int wpos = r;
+    int px = dst[2 * r], py = dst[2 * r + 1];
+    if (++r >= n) r = 0;
+    for (int i = 0; i < n && new_count > 2; i++) {
+        const int ex = dst[2 * r], ey = dst[2 * r + 1];
+        if (++r >= n) r = 0;
+        const int dx = ex - sx, dy = ey - sy;
+        int dist = (px - sx) * dy - (py - sy) * dx;
+        dist = dist < 0 ? -dist : dist;
+        if ((double)dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0) {
+            new_count--;
+            dst[2 * wpos] = sx = ex;
+            dst[2 * wpos + 1] = sy = ey;
+            if (++wpos >= n) wpos = 0;
+            px = dst[2 * r];
+            py = dst[2 * r + 1];
+            if (++r >= n) r = 0;
+            i++;
+            continue;
+        }
+        dst[2 * wpos] = sx = px;
+        dst[2 * wpos + 1] = sy = py;
+        if (++wpos >= n) wpos = 0;
+        px = ex;
+        py = ey;
+    }
+    return new_count;
+}
+
+// statistics + approximation + filter + publication of one stored border by the whole wave; false if the LDS stack
+// is too small for this border (the caller then falls back to the one-lane routine)
+template <bool CROP>
+__device__ bool wave_finish_border(const Workspace& ws, const StartCand c, const PlaneRef& pl, const int* pts, int npts, DpSlice* lds_stack) {
+    const TraceStats sp = wave_stats_of_points(pts, npts);
+    if (!worth_approximating(sp)) return true;
+    int dst[2 * (DP_MAX_OUT + 1)];
+    const int m = wave_approx_poly_dp(pts, npts, sp.perimeter * 0.02, dst, lds_stack);
+    if (m < 0) return false;
+    if (m == 4 && quad_filter(dst, pl.img_w, pl.img_h) && (threadIdx.x & 63) == 0) emit_quad<CROP>(ws, c, dst);
+    return true;
+}
+
 // Tiers 1 and 2, one lane per start, mask bytes read from global memory (one memory latency per step, 64 borders
 // per wave in flight).  Tier 1 sees every plausible start with a small step budget: most drop out or close within a
 // few steps (noise, staircase false starts).  Tier 2 re-follows the survivors of tier 1 -- now densely packed, a few
 // hundred steps each -- with a larger budget.  What outlives tier 2 (image-sized borders) goes to tier 3.
 // Returns true when the start must be queued for the next tier.
 template <bool CROP, int TIER>
-__device__ __forceinline__ bool follow_short(const Workspace& ws, const StartCand c) {
+__device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand c, int* slab_npts) {
     const int BUDGET = TIER == 1 ? SHORT_STEPS : ws.mid_steps;
     const PlaneRef pl = plane_of<CROP>(ws, c.roi);
     if (c.pos <= 0 || c.pos >= pl.plane) return false;
@@ -85,8 +282,13 @@ __device__ __forceinline__ bool follow_short(const Workspace& ws, const StartCan
         // tier 2 stores the points while it follows (lean loop, private slab): a border that fits needs no second
         // follow, and its statistics come from the stored points
         int* slab = ws.slab + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (4 * SLAB_PTS + 4);
-        const LeanTrace lt = trace_lean(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, slab, SLAB_PTS, BUDGET);
-        if (lt.status == TRACE_OVERRUN) return true;  // budget exhausted: a longer border
+        const bool timing = ws.dbg_follow_stop == 8;
+        const long long t0 = timing ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const LeanTrace lt = trace_lean(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, slab, ws.dbg_follow_stop == 7 ? 0 : SLAB_PTS, BUDGET);
+        if (ws.dbg_follow_stop == 7) return 0;
+        const long long t1 = timing ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        if (timing) atomicMax(reinterpret_cast<unsigned long long*>(ws.dbg + 4 * 8000), (unsigned long long)(t1 - t0));
+        if (lt.status == TRACE_OVERRUN) return 1;  // budget exhausted: a longer border
         if (ws.dbg_follow_stop == 9) {  // instrumentation: longest / total border length seen by tier 2
             atomicMax(ws.counters + 20, lt.steps);
             atomicAdd(ws.counters + 21, lt.steps);
@@ -94,15 +296,16 @@ __device__ __forceinline__ bool follow_short(const Workspace& ws, const StartCan
         }
         if (lt.status != TRACE_OK || lt.npts < 4) return false;
         if (lt.npts <= SLAB_PTS) {
-            const TraceStats sp = stats_of_points(slab, lt.npts);
-            if (!worth_approximating(sp) || ws.dbg_follow_stop == 1 || ws.dbg_follow_stop == 3) return false;
-            approximate_and_emit<CROP>(ws, c, pl, slab, sp.npts, sp.perimeter, reinterpret_cast<DpSlice*>(slab + 2 * SLAB_PTS));
-            return false;
+            if (ws.dbg_follow_stop == 1 || ws.dbg_follow_stop == 3) return false;
+            *slab_npts = lt.npts;   // finished by the whole wave, one border at a time (follow_kernel)
+            return 3;
         }
     }
     // tier 1, and tier-2 borders with more points than a slab holds: statistics first, then a storing follow
     const TraceStats st = trace_border<false, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
-    if (st.status == TRACE_OVERRUN) return true;
+    // budget exhausted: next tier -- or, from tier 1, straight to the wave tier when the border barely turned in 96 steps
+    // (image-sized straight borders would only burn tier 2's whole budget before getting there anyway)
+    if (st.status == TRACE_OVERRUN) return (TIER == 1 && st.npts <= 2) ? 2 : 1;
     if (!worth_approximating(st) || ws.dbg_follow_stop == 1) return false;
     const int need = 2 * st.npts + 2 * (st.npts + 2);
     const long long off = atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
@@ -119,6 +322,7 @@ __device__ __forceinline__ bool follow_short(const Workspace& ws, const StartCan
 
 template <bool CROP, int TIER>
 __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
+    __shared__ DpSlice wstack[4][WAVE_STACK];
     const StartCand* cands = TIER == 1 ? (CROP ? ws.cands_crop : ws.cands_frame) : (CROP ? ws.mid_crop : ws.mid_frame);
     StartCand* longs = TIER == 1 ? (CROP ? ws.mid_crop : ws.mid_frame) : (CROP ? ws.long_crop : ws.long_frame);
     int n = ws.counters[TIER == 1 ? (CROP ? CNT_CROP_CANDS : CNT_FRAME_CANDS) : (CROP ? CNT_MID_C : CNT_MID_F)];
@@ -127,30 +331,71 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
     int* ticket = ws.counters + (TIER == 1 ? (CROP ? CNT_TICKET_C : CNT_TICKET_F) : (CROP ? CNT_TICKET_MC : CNT_TICKET_MF));
     int* n_long = ws.counters + (TIER == 1 ? (CROP ? CNT_MID_C : CNT_MID_F) : (CROP ? CNT_LONG_C : CNT_LONG_F));
     const int lane = threadIdx.x & 63;
+    const long long t_begin = ws.dbg_follow_stop == 8 ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    int n_tickets = 0;
     for (;;) {
         int base = 0;
         if (lane == 0) base = atomicAdd(ticket, 64);
         base = __shfl(base, 0);
         if (base >= n) break;
+        n_tickets++;
         const int idx = base + lane;
         StartCand c;
         c.roi = 0; c.pos = 0; c.is_hole = 0;
-        bool queue = false;
+        int route = 0, slab_npts = 0;
         if (idx < n) {
             c = cands[idx];
-            queue = follow_short<CROP, TIER>(ws, c);
+            route = follow_short<CROP, TIER>(ws, c, &slab_npts);
         }
-        const unsigned long long mask = __ballot(queue);
-        if (mask) {
+        if (TIER == 2) {
+            // borders stored in the lanes' slabs: statistics, approximation and filter by the whole wave, one at a time
+            unsigned long long todo = __ballot(route == 3);
+            while (todo) {
+                const int L = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                StartCand cl;
+                cl.roi = __shfl(c.roi, L);
+                cl.pos = __shfl(c.pos, L);
+                cl.is_hole = __shfl(c.is_hole, L);
+                const int nl = __shfl(slab_npts, L);
+                const int* slab = ws.slab + ((size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63) + L) * (4 * SLAB_PTS + 4);
+                const PlaneRef pl = plane_of<CROP>(ws, cl.roi);
+                if (!wave_finish_border<CROP>(ws, cl, pl, slab, nl, wstack[threadIdx.x >> 6])) {
+                    // deeper recursion than the LDS stack holds: every lane runs the sequential routine on the same data
+                    // (stack in the owner's slab: identical writes), lane 0 publishes
+                    const TraceStats sp = stats_of_points(slab, nl);
+                    if (worth_approximating(sp))
+                        approximate_and_emit<CROP>(ws, cl, pl, slab, nl, sp.perimeter,
+                                                   reinterpret_cast<DpSlice*>(const_cast<int*>(slab) + 2 * SLAB_PTS), lane == 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int target = 1; target <= (TIER == 1 ? 2 : 1); target++) {
+            StartCand* list = (TIER == 1 && target == 2) ? (CROP ? ws.long_crop : ws.long_frame) : longs;
+            int* count = (TIER == 1 && target == 2) ? ws.counters + (CROP ? CNT_LONG_C : CNT_LONG_F) : n_long;
+            const bool queue = route == target;
+            const unsigned long long mask = __ballot(queue);
+            if (!mask) continue;
             int qbase = 0;
             const int leader = __ffsll((long long)mask) - 1;
-            if (lane == leader) qbase = atomicAdd(n_long, __popcll(mask));
+            if (lane == leader) qbase = atomicAdd(count, __popcll(mask));
             qbase = __shfl(qbase, leader);
             if (queue) {
                 const int slot = qbase + __popcll(mask & ((1ull << lane) - 1ull));
-                if (slot < ws.cap_long) longs[slot] = c;
+                if (slot < ws.cap_long) list[slot] = c;
                 else atomicOr(ws.counters + CNT_ERR, ERR_CAND_OVERFLOW);
             }
+        }
+    }
+    if (ws.dbg_follow_stop == 8 && TIER == 2 && lane == 0) {
+        const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (w < 8192) {
+            long long* d = ws.dbg + (size_t)(w + (CROP ? 4096 : 0)) * 4;
+            d[0] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
+            d[1] = n_tickets;
+            d[2] = n;
+            d[3] = t_begin;
         }
     }
 }
@@ -179,7 +424,7 @@ __device__ __forceinline__ void tile_load(TileCache& t, int x, int y, int bx = 0
     for (int cch = 0; cch < TILE / 16; cch++) {
         const int cx = t.tx0 + 16 * cch;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row >= 0 && row < t.sh && cx >= 0 && cx + 16 <= t.ns) v = *reinterpret_cast<const uint4*>(t.nbr + (long long)row * t.ns + cx);
+        if (row >= 0 && row < t.sh && cx >= 0 && cx + 16 <= t.ns) v = *reinterpret_cast<const uint4*>(t.nbr + nbr_addr(cx, row, t.ns));
         dst[cch] = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -351,9 +596,11 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
             // all lanes run statistics + approximation on the LDS points (same addresses: broadcast reads, identical
             // stack writes), lane 0 publishes
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            const TraceStats sp = stats_of_points(lp, lt.npts);
-            if (!worth_approximating(sp)) continue;
-            approximate_and_emit<CROP>(ws, c, pl, lp, sp.npts, sp.perimeter, reinterpret_cast<DpSlice*>(lp + 2 * LDS_PTS), lane == 0);
+            if (!wave_finish_border<CROP>(ws, c, pl, lp, lt.npts, reinterpret_cast<DpSlice*>(lp + 2 * LDS_PTS))) {
+                const TraceStats sp = stats_of_points(lp, lt.npts);
+                if (worth_approximating(sp))
+                    approximate_and_emit<CROP>(ws, c, pl, lp, sp.npts, sp.perimeter, reinterpret_cast<DpSlice*>(lp + 2 * LDS_PTS), lane == 0);
+            }
             continue;
         }
         // more points than the LDS buffer holds: store them in the pool with a second follow
@@ -422,7 +669,7 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
         const int sw = cw & ~1, sh = ch & ~1, ns = (sw + 15) & ~15;
         if (sw >= 2 && sh >= 2) {
             const int r = atomicAdd(ws.counters + CNT_CROP_ROIS, 1);
-            const long long plane = (long long)ns * sh;
+            const long long plane = nbr_plane_bytes(ns, sh);
             const long long off = (long long)atomicAdd(ws.crop_pixels, (unsigned long long)plane);
             const int ntx = (sw + MARCH_STRIP - 1) / MARCH_STRIP, nty = (sh + MARCH_CROP_ROWS - 1) / MARCH_CROP_ROWS;
             if (r >= ws.cap_crop_rois || off + plane > ws.cap_crop_pixels) {

@@ -24,6 +24,20 @@ OCVAR_HD int dir_dy(int s) { return (s >= 1 && s <= 3) ? -1 : ((s >= 5 && s <= 7
 
 struct Pt { int x, y; };
 
+// Byte offset of pixel (x,y) in a neighbour-mask plane of row stride ns (a multiple of 16).
+// Product build (OCVAR_NBR_TILED): the plane is stored as 16x8-pixel tiles of 128 contiguous bytes -- one cache
+// line -- because the border follower walks locally in 2-D: with raster rows every vertical step of a border is
+// a new 128-byte line (a fresh HBM/MALL miss on a dependent chain), with tiles a walk stays in a line for ~10 steps.
+// The host-side test build of the cores keeps plain raster planes.
+OCVAR_HD long long nbr_addr(int x, int y, int ns) {
+#if defined(OCVAR_NBR_TILED)
+    return ((long long)((y >> 3) * (ns >> 4) + (x >> 4)) << 7) + ((y & 7) << 4) + (x & 15);
+#else
+    return (long long)y * ns + x;
+#endif
+}
+OCVAR_HD long long nbr_plane_bytes(int ns, int sh) { return (long long)ns * ((sh + 7) & ~7); }
+
 // One region of interest handed to the square finder: a whole frame (frame pass) or the clipped
 // bounding box of a frame-pass quad (crop pass, opencvar.cpp:682-693).
 struct Roi {

@@ -16,7 +16,7 @@ constexpr int MARCH_CROP_ROWS = 256;       // rows per work unit in the crop pas
 constexpr int MARCH_STAGE = 512;           // border starts a wave stages in LDS between two appends to the global list
 constexpr int BACK_STEPS = 32;
 constexpr int SHORT_STEPS = 96;            // step budget of follower tier 1 (every plausible start, one lane each)
-constexpr int MID_STEPS = 3072;            // step budget of tier 2 (borders that outlived tier 1, one lane each); the rest: tier 3, one wave each
+constexpr int MID_STEPS = 1536;            // step budget of tier 2 (borders that outlived tier 1, one lane each); the rest: tier 3, one wave each
 constexpr int SLAB_PTS = 1024;             // points a tier-2 lane can keep in its private slab (no second follow needed below that)
 constexpr int MID_BLOCKS = 512;            // tier-2 grid (x256 threads, one slab each)
 constexpr int LDS_PTS = 512;               // points a tier-3 wave can keep in LDS
@@ -84,6 +84,7 @@ struct Workspace {
     TemplateRec* templates; // [MAXT]
     CameraRec* camera;
     int* counters;          // [CNT_COUNT]
+    long long* dbg;         // [8192][4] per-wave instrumentation (cycles, steps, tickets, kernel tag); experiments only
 };
 
 // launchers (each enqueues on `stream`, no synchronisation)

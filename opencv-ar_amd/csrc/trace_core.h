@@ -70,7 +70,7 @@ OCVAR_HD TraceStats trace_border(const uint8_t* nbr, int sw, int plane, int cpos
     st.steps = 0;
     const int i0 = cpos - is_hole;
     int x = i0 % sw, y = i0 / sw;
-    unsigned m = nbr[i0];
+    unsigned m = nbr[nbr_addr(x, y, sw)];
     if (m == 0) {  // single-pixel domain (only reachable for outer borders)
         st.status = TRACE_SINGLE;
         st.npts = 1;
@@ -131,7 +131,7 @@ OCVAR_HD TraceStats trace_border(const uint8_t* nbr, int sw, int plane, int cpos
             st.status = TRACE_OVERRUN;
             return st;
         }
-        unsigned m4 = nbr[i4];
+        unsigned m4 = nbr[nbr_addr(x, y, sw)];
         if (m4 == 0) {
             st.status = TRACE_OVERRUN;
             return st;
@@ -147,9 +147,9 @@ OCVAR_HD TraceStats trace_border(const uint8_t* nbr, int sw, int plane, int cpos
             while (!landed && !closed) {
                 unsigned long long ahead = 0;
                 for (int t = 1; t <= 8; t++) {
-                    int qi = p + t * d;
-                    qi = qi < 0 ? 0 : (qi >= plane ? plane - 1 : qi);
-                    ahead |= (unsigned long long)nbr[qi] << (8 * (t - 1));
+                    const int qi = p + t * d;
+                    const bool ok = qi >= 0 && qi < plane;   // (x,y) is the position of p here
+                    ahead |= (unsigned long long)(ok ? nbr[nbr_addr(x + t * ddx, y + t * ddy, sw)] : 0) << (8 * (t - 1));
                 }
                 for (int t = 1; t <= 8; t++) {
                     // p carries mask m and leaves in direction s: its scan positions, then the step p -> q
@@ -195,7 +195,8 @@ OCVAR_HD TraceStats trace_border(const uint8_t* nbr, int sw, int plane, int cpos
 // ---- lean follower -------------------------------------------------------------------------------------------
 // Same stepping rules as trace_border, stripped to the dependent chain: no statistics while walking (they are
 // recomputed from the stored points afterwards), direction deltas from packed 2-bit tables, the examined-neighbour
-// test as one rotated bit mask.  Stores up to max_pts points; npts keeps counting beyond that.
+// test as one rotated bit mask.  Stores up to max_pts points (out must hold max_pts + 1: one scratch slot); npts keeps
+// counting beyond that.
 struct LeanTrace {
     int status;
     int npts;
@@ -212,7 +213,7 @@ OCVAR_HD LeanTrace trace_lean(const uint8_t* nbr, int ns, int plane, int cpos, i
     r.steps = 0;
     const int i0 = cpos - is_hole;
     int x = i0 % ns, y = i0 / ns;
-    unsigned m = nbr[i0];
+    unsigned m = nbr[nbr_addr(x, y, ns)];
     if (m == 0) {
         r.status = TRACE_SINGLE;
         r.npts = 1;
@@ -236,25 +237,39 @@ OCVAR_HD LeanTrace trace_lean(const uint8_t* nbr, int ns, int plane, int cpos, i
             r.status = TRACE_NOT_FIRST;
             break;
         }
-        if (e != prev_s) {
-            if (r.npts < max_pts) {
-                out[2 * r.npts] = x;
-                out[2 * r.npts + 1] = y;
-            }
-            r.npts++;
-            prev_s = e;
-        }
+        const bool emit = e != prev_s;   // CHAIN_APPROX_SIMPLE: a point wherever the direction changes
+        const int ex = x, ey = y;
+        prev_s = e;
         const int dx = step_dx(e), dy = step_dy(e);
         const int nidx = idx + dy * ns + dx;
         x += dx;
         y += dy;
-        if (nidx == i0 && idx == i1) break;
+        if (nidx == i0 && idx == i1) {
+            if (emit) {
+                if (r.npts < max_pts) {
+                    out[2 * r.npts] = ex;
+                    out[2 * r.npts + 1] = ey;
+                }
+                r.npts++;
+            }
+            break;
+        }
         if ((unsigned)nidx >= (unsigned)plane) {
             r.status = TRACE_OVERRUN;
             break;
         }
         idx = nidx;
-        m = nbr[idx];
+        // The next step's mask is requested BEFORE this step's point is stored, and the store is unconditional
+        // (non-points go to a scratch slot behind the last point): memory operations retire in order, so the wait for
+        // the mask must be able to leave exactly these two younger stores in flight -- which the compiler can only
+        // count when they are on the straight-line path.
+        m = nbr[nbr_addr(x, y, ns)];
+        if (max_pts > 0) {
+            const int slot = (emit && r.npts < max_pts) ? r.npts : max_pts;
+            out[2 * slot] = ex;
+            out[2 * slot + 1] = ey;
+        }
+        r.npts += emit ? 1 : 0;
         if (m == 0) {
             r.status = TRACE_OVERRUN;
             break;
@@ -275,18 +290,29 @@ OCVAR_HD TraceStats stats_of_points(const int* pts, int n) {
     st.maxx = st.maxy = -0x7fffffff;
     st.perimeter = 0.0;
     int px = pts[2 * (n - 1)], py = pts[2 * (n - 1) + 1];
-    for (int i = 0; i < n; i++) {
-        const int x = pts[2 * i], y = pts[2 * i + 1];
-        st.minx = x < st.minx ? x : st.minx;
-        st.maxx = x > st.maxx ? x : st.maxx;
-        st.miny = y < st.miny ? y : st.miny;
-        st.maxy = y > st.maxy ? y : st.maxy;
-        if (n > 1) {
-            const float dx = (float)x - (float)px, dy = (float)y - (float)py;
-            st.perimeter += (double)sqrt_rn(dx * dx + dy * dy);
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        int xs[8], ys[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int q = i0 + k < n ? i0 + k : n - 1;
+            xs[k] = pts[2 * q];
+            ys[k] = pts[2 * q + 1];
         }
-        px = x;
-        py = y;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (i0 + k >= n) break;
+            const int x = xs[k], y = ys[k];
+            st.minx = x < st.minx ? x : st.minx;
+            st.maxx = x > st.maxx ? x : st.maxx;
+            st.miny = y < st.miny ? y : st.miny;
+            st.maxy = y > st.maxy ? y : st.maxy;
+            if (n > 1) {
+                const float dx = (float)x - (float)px, dy = (float)y - (float)py;
+                st.perimeter += (double)sqrt_rn(dx * dx + dy * dy);
+            }
+            px = x;
+            py = y;
+        }
     }
     return st;
 }
@@ -299,20 +325,25 @@ OCVAR_HD TraceStats stats_of_points(const int* pts, int n) {
 // the arrival direction is the first non-zero neighbour clockwise from exit-1.
 OCVAR_HD bool earlier_start_behind(const uint8_t* nbr, int sw, int plane, int cpos, int is_hole, int max_back) {
     const int i0 = cpos - is_hole;
-    unsigned m = nbr[i0];
+    int x = i0 % sw, y = i0 / sw;
+    unsigned m = nbr[nbr_addr(x, y, sw)];
     if (m == 0) return false;
     const int b0 = first_cw(m, (is_hole ? 0 : 4) - 1);
     int q = i0 + dir_dy(b0) * sw + dir_dx(b0);
+    x += dir_dx(b0);
+    y += dir_dy(b0);
     int s = (b0 + 4) & 7;  // exit direction at q (towards the pixel we came from)
     for (int k = 0; k < max_back; k++) {
         if ((unsigned)q >= (unsigned)plane) return false;
-        m = nbr[q];
+        m = nbr[nbr_addr(x, y, sw)];
         if (m == 0) return false;
         const int b = first_cw(m, s - 1);
         if (q == i0 && b == b0) return false;  // back at the start visit: whole lap, nothing earlier
         const int examined = (s - (b + 1)) & 7;
         if ((((4 - (b + 1)) & 7) < examined && q < cpos) || (((0 - (b + 1)) & 7) < examined && q + 1 < cpos)) return true;
         q += dir_dy(b) * sw + dir_dx(b);
+        x += dir_dx(b);
+        y += dir_dy(b);
         s = (b + 4) & 7;
     }
     return false;
@@ -340,14 +371,27 @@ OCVAR_HD int approx_poly_dp(const int* src, int count, double parameter, int* ds
         pos = (pos + right.start) % count;
         sx = src[2 * pos];
         sy = src[2 * pos + 1];
-        int q = pos;
-        for (int j = 1; j < count; j++) {
-            if (++q >= count) q = 0;
-            int dx = src[2 * q] - sx, dy = src[2 * q + 1] - sy;
-            int dist = dx * dx + dy * dy;
-            if (dist > max_dist) {
-                max_dist = dist;
-                right.start = j;
+        // points are fetched 8 at a time (independent loads first, then the dependent max-search): one memory
+        // latency per 8 points instead of one per point when the contour lives in global memory
+        for (int j0 = 1; j0 < count; j0 += 8) {
+            int px[8], py[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                int q = pos + j0 + k;
+                q = q >= count ? q - count : q;
+                q = q >= count ? 0 : q;   // lanes past the end read a valid slot and are ignored below
+                px[k] = src[2 * q];
+                py[k] = src[2 * q + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (j0 + k >= count) break;
+                const int dx = px[k] - sx, dy = py[k] - sy;
+                const int dist = dx * dx + dy * dy;
+                if (dist > max_dist) {
+                    max_dist = dist;
+                    right.start = j0 + k;
+                }
             }
         }
         le_eps = (float)max_dist <= eps;
@@ -376,14 +420,25 @@ OCVAR_HD int approx_poly_dp(const int* src, int count, double parameter, int* ds
         if (slice.end > slice.start + 1) {
             const int dx = ex - sx, dy = ey - sy;
             int max_dist = 0;
-            int q = b;
-            for (int i = slice.start + 1; i < slice.end; i++) {
-                if (++q >= count) q = 0;
-                int d = (src[2 * q + 1] - sy) * dx - (src[2 * q] - sx) * dy;
-                d = d < 0 ? -d : d;
-                if (d > max_dist) {
-                    max_dist = d;
-                    right.start = i;
+            for (int i0 = slice.start + 1; i0 < slice.end; i0 += 8) {
+                int px[8], py[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    int q = i0 + k;                      // indices run up to < 2*count
+                    q = q >= count ? q - count : q;
+                    q = q >= count ? 0 : q;
+                    px[k] = src[2 * q];
+                    py[k] = src[2 * q + 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (i0 + k >= slice.end) break;
+                    int d = (py[k] - sy) * dx - (px[k] - sx) * dy;
+                    d = d < 0 ? -d : d;
+                    if (d > max_dist) {
+                        max_dist = d;
+                        right.start = i0 + k;
+                    }
                 }
             }
             le_eps = (double)max_dist * max_dist <= (double)eps * ((double)dx * dx + (double)dy * dy);

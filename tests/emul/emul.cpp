@@ -54,7 +54,7 @@ extern "C" int emul_find_contours(const uint8_t* bin, int w, int h, int* pts, in
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), w, w * h, y * w + x, 0, g_back)) { g_back_drops++; continue; }
             TraceStats st;
             if (g_lean) {
-                LeanTrace lt = trace_lean(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, buf.data(), (int)buf.size() / 2, 4 * w * h + 16);
+                LeanTrace lt = trace_lean(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, buf.data(), (int)buf.size() / 2 - 1, 4 * w * h + 16);
                 st.status = lt.status;
                 st.npts = lt.npts;
                 if (lt.status == TRACE_SINGLE) { buf[0] = x; buf[1] = y; }
@@ -129,7 +129,7 @@ extern "C" int emul_find_squares_bin(const uint8_t* bin, int sw, int sh, int img
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, 0, g_back)) { g_back_drops++; continue; }
             st_[0]++;
             if (g_lean) {   // the tier-2/3 flow: store while following, statistics from the stored points
-                buf.resize(2 * 4096);
+                buf.resize(2 * 4097);
                 LeanTrace lt = trace_lean(nbr.data(), sw, sw * sh, y * sw + x, hole, buf.data(), 4096, 4 * sw * sh + 16);
                 if (lt.status == TRACE_OVERRUN || lt.npts > 4096) return -3;
                 if (lt.status != TRACE_OK) continue;
