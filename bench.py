@@ -44,7 +44,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step (over all streams)")
+    ap.add_argument("--streams", type=int, default=4, help="independent detector contexts / HIP streams per GPU; the batch is split over them")
     ap.add_argument("--unique", type=int, default=16, help="distinct synthetic frames per GPU (tiled to the batch)")
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config id (3 = headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -75,29 +76,43 @@ def main():
     frames = np.concatenate([base] * ((B + uniq - 1) // uniq))[:B]
     tpls = H.oracle_templates(names)   # template codes / camera are setup-side data structures
     cam = H.oracle_camera(W, Hh)
-    det = oa.Detector(W, Hh, max_batch=B, device=local_rank)
-    det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls])
-    det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+    # The batch is split over `streams` independent contexts, each with its own HIP stream and workspace, so that the
+    # latency-bound kernels of one sub-batch (border following) overlap the streaming kernels of another.
+    NS = max(1, min(args.streams, B))
+    sub = [B // NS + (1 if i < B % NS else 0) for i in range(NS)]
+    offs = np.concatenate([[0], np.cumsum(sub)]).astype(int)
+    dets, streams = [], []
+    for i in range(NS):
+        det = oa.Detector(W, Hh, max_batch=sub[i], device=local_rank)
+        det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls])
+        det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+        dets.append(det)
+        streams.append(torch.cuda.Stream())
+    det = dets[0]
     d_frames = torch.from_numpy(frames).cuda()
-    stream = torch.cuda.Stream()
-    nbytes_m = B * S.MAX_MARKERS * S.MARKER_BYTES
+    frame_bytes = W * Hh * 3
     d_res = torch.empty(S.block_bytes(B), dtype=torch.uint8, device="cuda")
+    nbytes_m = B * S.MAX_MARKERS * S.MARKER_BYTES
 
-    stage_sum = np.zeros(8, np.float64)
+    stage_sum = np.zeros(12, np.float64)
 
     def step(timed):
-        det.enqueue_device(d_frames.data_ptr(), W, Hh, B, stream=stream.cuda_stream)
+        for i in range(NS):
+            dets[i].enqueue_device(d_frames.data_ptr() + int(offs[i]) * frame_bytes, W, Hh, sub[i], stream=streams[i].cuda_stream)
+            if world > 1:
+                dets[i].results_to_device(d_res.data_ptr() + int(offs[i]) * S.MAX_MARKERS * S.MARKER_BYTES,
+                                          d_res.data_ptr() + nbytes_m + 4 * int(offs[i]), streams[i].cuda_stream)
+        parts = [dets[i].collect(8) for i in range(NS)]
+        markers = np.concatenate([p[0] for p in parts])
+        counts = np.concatenate([p[1] for p in parts])
         if world > 1:
-            det.results_to_device(d_res.data_ptr(), d_res.data_ptr() + nbytes_m, stream.cuda_stream)
-        markers, counts = det.collect(8)
-        if world > 1:
-            with torch.cuda.stream(stream):
-                blocks = S.gather_blocks(d_res, rank, world, dist)
-            stream.synchronize()
+            blocks = S.gather_blocks(d_res, rank, world, dist)   # all sub-batches are complete (collect waited)
+            torch.cuda.current_stream().synchronize()
             if rank == 0 and not timed:
                 S.unpack(blocks, B, oa.MARKER_DTYPE)  # warm-up only: checks the gathered blocks decode
         if timed:
-            stage_sum[:] += det.stage_ms()
+            for i in range(NS):
+                stage_sum[:] += dets[i].stage_ms() * (sub[i] / B)   # batch-weighted mean over the contexts
         return markers, counts
 
     for _ in range(args.warmup):
@@ -117,42 +132,69 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # Outside the timed region: per-kernel durations of launches that run alone on the GPU (one context, its
+    # sub-batch).  With several streams the timed region's launches overlap each other, so their event-to-event
+    # durations include time shared with other kernels; these isolated durations are what a roofline of the kernel itself
+    # should be read against.  Reported separately, never mixed into `value`.
+    iso = np.zeros(12, np.float64)
+    for _ in range(3):
+        dets[0].enqueue_device(d_frames.data_ptr(), W, Hh, sub[0], stream=streams[0].cuda_stream)
+        dets[0].collect(8)
+        iso += dets[0].stage_ms() / 3
+
     if rank == 0:
         K = args.steps
         fps = world * B * K / dt
         stage_ms = stage_sum / K
-        cnt = det.counters()
-        crop_pixels = float(cnt[4]) / B if len(cnt) > 4 else 0.0
+        crop_pixels = sum(float(d.counters()[4]) for d in dets) / B
         n_out = float(counts.sum()) / B
         # algorithmic bytes per frame = 6*W*H + sum of crop areas + 184 per output marker
         alg_frame = 6.0 * W * Hh + crop_pixels + 184.0 * n_out
-        # dominant kernel by measured time; its algorithmic bytes per launch ("kernels")
+        # Per-kernel mean launch duration (HIP events on the launch streams, timed region) and algorithmic bytes per
+        # launch; one launch covers one sub-batch of Bs frames.
+        Bs = B / NS
+        WH = float(W * Hh)
         kernels = [
-            ("binarise_frames_kernel", 0, 5.0 * W * Hh * B),            # 3 B BGR read + 1 B grey + 1 B mask per pixel
-            ("follow_kernel<frames>", 1, 1.0 * W * Hh * B),              # one read of the mask plane
-            ("binarise_crops_kernel", 3, 2.0 * crop_pixels * B),         # grey crop read + mask write
-            ("follow_kernel<crops>", 4, 1.0 * crop_pixels * B),
+            ("binarise_frames_kernel", 0, 5.0 * WH * Bs),          # 3 B BGR read + 1 B grey + 1 B mask per pixel
+            ("follow_kernel<frames,1>", 1, 1.0 * WH * Bs / 16),     # touches masks near borders only; bound: latency
+            ("follow_kernel<frames,2>", 2, 1.0 * WH * Bs / 16),
+            ("follow_long_kernel<frames>", 3, 1.0 * WH * Bs / 16),
+            ("binarise_crops_kernel", 5, 2.0 * crop_pixels * Bs),   # grey crop read + mask write
+            ("follow_kernel<crops,1>", 6, 1.0 * crop_pixels * Bs / 16),
+            ("follow_kernel<crops,2>", 7, 1.0 * crop_pixels * Bs / 16),
+            ("follow_long_kernel<crops>", 8, 1.0 * crop_pixels * Bs / 16),
         ]
         dom = max(kernels, key=lambda k: stage_ms[k[1]])
         ach = dom[2] / (stage_ms[dom[1]] * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tf):   # HBM bytes per frame from rocprofv3 PMC passes (tools/collect_traffic.py), scaled to a launch
+            t = json.load(open(tf)).get(dom[0].split("<")[0] if dom[0].startswith("binarise") else dom[0])
+            if t and t.get("width") == W and t.get("height") == Hh:
+                traffic = round(t["hbm_bytes_per_frame"] * Bs)
         out = {
             "metric": "frames/sec at 1920x1080, 16 markers/frame; 1/2/4/8 MI355X", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / K, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"configs[2]: {W}x{Hh}, {cfg.grid_x * cfg.grid_y} markers/frame, templates "
                                    f"{'2x2' if names else '2x2/3x3/4x4 x 4 rotations'}, batch {B} frames/GPU/step "
-                                   f"({uniq} distinct), stateless", "frames_per_step_per_gpu": B,
+                                   f"({uniq} distinct) in {NS} stream(s), stateless", "frames_per_step_per_gpu": B, "streams": NS,
                        "parallelism": f"frame-sharded x{world}" + (", RCCL gather of CvarMarker arrays" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None},
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "launch_ms": round(float(stage_ms[dom[1]]), 4), "alg_bytes_per_launch": round(dom[2])},
             "pipeline_roofline": {"bound": "hbm", "achieved": round(alg_frame * fps / world / 1e9, 2), "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": round(alg_frame * fps / world / 1e9 / HBM_PEAK_GBS, 5),
                                   "alg_bytes_per_frame": round(alg_frame)},
-            "binarise_roofline": {"achieved": round(5.0 * W * Hh * B / (stage_ms[0] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": round(5.0 * W * Hh * B / (stage_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-            "stage_ms": {k: round(float(v), 4) for k, v in zip(
-                ["binarise_frames", "follow_frames", "order_crops", "binarise_crops", "follow_crops", "decode",
-                 "dedupe_pose", "batch_total"], stage_ms)},
+            "binarise_roofline": {"kernel": "binarise_frames_kernel", "bound": "hbm", "achieved": round(5.0 * WH * Bs / (stage_ms[0] * 1e-3) / 1e9, 2),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(5.0 * WH * Bs / (stage_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                  "launch_ms": round(float(stage_ms[0]), 4)},
+            "stage_ms": {k: round(float(v), 4) for k, v in zip(oa.STAGE_NAMES, stage_ms)},
+            "isolated_launch_ms": {k: round(float(v), 4) for k, v in zip(oa.STAGE_NAMES, iso)},
+            "binarise_roofline_isolated": {"kernel": "binarise_frames_kernel", "bound": "hbm", "frames_per_launch": sub[0],
+                                           "achieved": round(5.0 * WH * sub[0] / (iso[0] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(5.0 * WH * sub[0] / (iso[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                           "note": "same kernel, launches not overlapped by other streams (outside the timed region)"},
             "markers_per_frame": round(n_out, 3),
         }
         if not args.no_cpu_baseline:

@@ -103,9 +103,13 @@ int ocvar_hip_debug_binary(OcvarHip* ctx, int frame, uint8_t* h_bin /* (w&~1)*(h
 int ocvar_hip_debug_frame_quads(OcvarHip* ctx, int frame, int* quads /* OCVAR_MAX_QUADS*8 */, int* n_quads);
 int ocvar_hip_debug_candidates(OcvarHip* ctx, int frame, OcvarCandidate* cands, int max_cands, int* n_cands);
 
-/* Per-stage device time of the last enqueue in milliseconds (HIP events on the launch stream):
- * [0] binarise(frame) [1] follow+approx(frame) [2] order/crops [3] binarise(crops) [4] follow+approx(crops)
- * [5] decode [6] dedupe+pose [7] whole batch.  Returns the number of entries written. */
+/* Measurement aid: runs a dword-per-lane copy of `bytes` bytes (the binarise kernel's access widths) so that a
+ * rocprofv3 PMC pass can calibrate FETCH_SIZE / WRITE_SIZE for that pattern (tools/collect_traffic.py). */
+int ocvar_hip_debug_calibrate(OcvarHip* ctx, size_t bytes);
+
+/* Per-kernel device time of the last enqueue in milliseconds (HIP events on the launch stream), 12 entries:
+ * [0] binarise(frames) [1..3] follower tiers 1,2,3 (frames) [4] order/crops [5] binarise(crops)
+ * [6..8] follower tiers 1,2,3 (crops) [9] decode [10] dedupe+pose [11] whole batch.  Returns the number written. */
 int ocvar_hip_stage_ms(OcvarHip* ctx, float* ms, int n);
 /* Work counters of the last batch: [0] frame start candidates [1] crop ROIs [2] crop tiles
  * [3] crop start candidates [4] sum of crop areas (pixels) [5] point-pool ints used. */

@@ -24,8 +24,10 @@ HIP_SYMBOLS = [
     "ocvar_hip_create", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
     "ocvar_hip_detect_device", "ocvar_hip_enqueue", "ocvar_hip_collect", "ocvar_hip_detect_host", "ocvar_hip_find_squares",
     "ocvar_hip_debug_gray", "ocvar_hip_debug_binary", "ocvar_hip_debug_frame_quads", "ocvar_hip_debug_candidates",
-    "ocvar_hip_stage_ms", "ocvar_hip_counters", "ocvar_hip_results_to_device",
+    "ocvar_hip_stage_ms", "ocvar_hip_counters", "ocvar_hip_results_to_device", "ocvar_hip_debug_calibrate",
 ]
+STAGE_NAMES = ["binarise_frames", "follow1_frames", "follow2_frames", "follow3_frames", "order_crops", "binarise_crops",
+               "follow1_crops", "follow2_crops", "follow3_crops", "decode", "dedupe_pose", "batch_total"]
 
 
 class Camera(C.Structure):  # CvarCamera, reference include/opencvar/opencvar.h:54-60
@@ -93,6 +95,7 @@ def hip_lib():
         lib.ocvar_hip_stage_ms.argtypes = [vp, vp, i]
         lib.ocvar_hip_counters.argtypes = [vp, vp, i]
         lib.ocvar_hip_results_to_device.argtypes = [vp, vp, vp, vp]
+        lib.ocvar_hip_debug_calibrate.argtypes = [vp, sz]
         _hip = lib
     return _hip
 
@@ -225,11 +228,11 @@ class Detector:
         return [arr[i] for i in range(min(n.value, max_cands))]
 
     def stage_ms(self):
-        ms = np.zeros(8, np.float32)
-        k = self._lib.ocvar_hip_stage_ms(self._ctx, _ptr(ms), 8)
+        ms = np.zeros(12, np.float32)
+        k = self._lib.ocvar_hip_stage_ms(self._ctx, _ptr(ms), 12)
         return ms[:max(k, 0)]
 
     def counters(self):
-        out = np.zeros(9, np.int64)
-        k = self._lib.ocvar_hip_counters(self._ctx, _ptr(out), 9)
+        out = np.zeros(6, np.int64)
+        k = self._lib.ocvar_hip_counters(self._ctx, _ptr(out), 6)
         return out[:max(k, 0)]

@@ -23,7 +23,7 @@ struct OcvarHip {
     Workspace ws{};
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;
-    hipEvent_t ev[9]{};
+    hipEvent_t ev[13]{};   // 12 intervals: see ocvar_hip_stage_ms
     std::vector<void*> allocs;
     uint8_t* d_frames = nullptr;  // staging for the host-buffer entry points
     size_t d_frames_bytes = 0;
@@ -116,8 +116,7 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     if ((rc = dev_alloc(c, &w.templates, (size_t)MAXT))) return rc;
     if ((rc = dev_alloc(c, &w.camera, (size_t)1))) return rc;
     if ((rc = dev_alloc(c, &w.counters, (size_t)CNT_COUNT))) return rc;
-    if ((rc = dev_alloc(c, &w.dbg, (size_t)8192 * 4))) return rc;
-    HIP_TRY(c, hipMemset(w.dbg, 0, 8192 * 4 * sizeof(long long)));
+
     w.crop_pixels = reinterpret_cast<unsigned long long*>(w.counters + CNT_CROP_PIXELS);
     HIP_TRY(c, hipMemset(w.n_prev, 0, B * sizeof(int)));
     HIP_TRY(c, hipMemset(w.counters, 0, CNT_COUNT * sizeof(int)));
@@ -182,7 +181,6 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     w.n_frames = n_frames;
     w.mid_steps = std::getenv("OCVAR_MID_STEPS") ? std::atoi(std::getenv("OCVAR_MID_STEPS")) : MID_STEPS;
     w.long_blocks = std::getenv("OCVAR_LONG_BLOCKS") ? std::atoi(std::getenv("OCVAR_LONG_BLOCKS")) : 1024;
-    w.dbg_follow_stop = std::getenv("OCVAR_DBG_FOLLOW_STOP") ? std::atoi(std::getenv("OCVAR_DBG_FOLLOW_STOP")) : 0;
     w.frame_strips = (w.sw + MARCH_STRIP - 1) / MARCH_STRIP;
     {   // rows per binarise work unit: about 128, even, chunks of equal size
         int chunks = (w.sh + 64) / 128;
@@ -204,29 +202,33 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     launch_binarise_frames(w, d_bgr, row_stride, frame_stride, grey_in_place, s);
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     launch_follow_frames(w, s);
-    launch_follow_mid_frames(w, s);
-    launch_follow_long_frames(w, s);
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
-    launch_order_and_crops(w, s);
+    launch_follow_mid_frames(w, s);
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    launch_follow_long_frames(w, s);
+    HIP_TRY(c, hipEventRecord(c->ev[4], s));
+    launch_order_and_crops(w, s);
+    HIP_TRY(c, hipEventRecord(c->ev[5], s));
     if (stages > 2) {
         launch_binarise_crops(w, s);
-        HIP_TRY(c, hipEventRecord(c->ev[4], s));
-        launch_follow_crops(w, s);
-        launch_follow_mid_crops(w, s);
-        launch_follow_long_crops(w, s);
-        HIP_TRY(c, hipEventRecord(c->ev[5], s));
-        launch_decode(w, s);
         HIP_TRY(c, hipEventRecord(c->ev[6], s));
-        launch_finalise(w, s);
+        launch_follow_crops(w, s);
         HIP_TRY(c, hipEventRecord(c->ev[7], s));
+        launch_follow_mid_crops(w, s);
+        HIP_TRY(c, hipEventRecord(c->ev[8], s));
+        launch_follow_long_crops(w, s);
+        HIP_TRY(c, hipEventRecord(c->ev[9], s));
+        launch_decode(w, s);
+        HIP_TRY(c, hipEventRecord(c->ev[10], s));
+        launch_finalise(w, s);
+        HIP_TRY(c, hipEventRecord(c->ev[11], s));
         HIP_TRY(c, hipMemcpyAsync(c->h_counts, w.n_markers, n_frames * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipMemcpyAsync(c->h_markers, w.markers, (size_t)n_frames * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToHost, s));
     } else {
-        for (int k = 4; k < 8; k++) HIP_TRY(c, hipEventRecord(c->ev[k], s));
+        for (int k = 6; k < 12; k++) HIP_TRY(c, hipEventRecord(c->ev[k], s));
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, w.counters, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipEventRecord(c->ev[8], s));
+    HIP_TRY(c, hipEventRecord(c->ev[12], s));
     HIP_TRY(c, hipGetLastError());
     c->last_stream = s;
     c->pending = true;
@@ -263,7 +265,7 @@ extern "C" int ocvar_hip_results_to_device(OcvarHip* c, OcvarMarker* d_markers, 
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->last_stream;
     if (s != c->last_stream) {  // order behind the batch
-        HIP_TRY(c, hipStreamWaitEvent(s, c->ev[8], 0));
+        HIP_TRY(c, hipStreamWaitEvent(s, c->ev[12], 0));
     }
     const int n = c->ws.n_frames;
     HIP_TRY(c, hipMemcpyAsync(d_markers, c->ws.markers, (size_t)n * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToDevice, s));
@@ -417,18 +419,33 @@ extern "C" int ocvar_hip_debug_candidates(OcvarHip* c, int frame, OcvarCandidate
 extern "C" int ocvar_hip_stage_ms(OcvarHip* c, float* ms, int n) {
     if (!c || !ms || n < 1 || c->pending) return OCVAR_E_ARG;
     int k = 0;
-    for (; k < 7 && k < n; k++)
+    for (; k < 11 && k < n; k++)
         if (hipEventElapsedTime(&ms[k], c->ev[k], c->ev[k + 1]) != hipSuccess) ms[k] = -1.f;
-    if (k < n && k == 7) {
-        if (hipEventElapsedTime(&ms[7], c->ev[0], c->ev[8]) != hipSuccess) ms[7] = -1.f;
-        k = 8;
+    if (k < n && k == 11) {
+        if (hipEventElapsedTime(&ms[11], c->ev[0], c->ev[12]) != hipSuccess) ms[11] = -1.f;
+        k = 12;
     }
     return k;
 }
 
-extern "C" int ocvar_hip_debug_waves(OcvarHip* c, long long* out /* 8192*4 */) {
-    if (!c || !out) return OCVAR_E_ARG;
-    HIP_TRY(c, hipMemcpy(out, c->ws.dbg, 8192 * 4 * sizeof(long long), hipMemcpyDeviceToHost));
+// Calibration load for rocprofv3's FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md, HBM section: the
+// counters are only calibrated for 16-byte-per-lane streams): copies `bytes` with the access widths the binarise kernel
+// uses (one dword per lane, coalesced), so a profile of this launch gives bytes-per-counter-unit for that pattern.
+__global__ void calib_copy_dword_kernel(const unsigned* src, unsigned* dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i] + 1u;
+}
+
+extern "C" int ocvar_hip_debug_calibrate(OcvarHip* c, size_t bytes) {
+    if (!c || bytes < 1024) return OCVAR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned *a = nullptr, *b = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&a, bytes));
+    HIP_TRY(c, hipMalloc((void**)&b, bytes));
+    HIP_TRY(c, hipMemset(a, 1, bytes));
+    hipLaunchKernelGGL(calib_copy_dword_kernel, dim3(4096), dim3(256), 0, c->stream, a, b, bytes / 4);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(a);
+    (void)hipFree(b);
     return OCVAR_OK;
 }
 
@@ -440,6 +457,5 @@ extern "C" int ocvar_hip_counters(OcvarHip* c, long long* out, int n) {
                       (long long)*reinterpret_cast<const unsigned long long*>(h + CNT_POOL_INTS)};
     int k = 0;
     for (; k < 6 && k < n; k++) out[k] = v[k];
-    for (; k < 9 && k < n; k++) out[k] = h[20 + (k - 6)];  // instrumentation slots
     return k;
 }

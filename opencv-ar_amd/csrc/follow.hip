@@ -282,21 +282,10 @@ __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand
         // tier 2 stores the points while it follows (lean loop, private slab): a border that fits needs no second
         // follow, and its statistics come from the stored points
         int* slab = ws.slab + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (4 * SLAB_PTS + 4);
-        const bool timing = ws.dbg_follow_stop == 8;
-        const long long t0 = timing ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        const LeanTrace lt = trace_lean(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, slab, ws.dbg_follow_stop == 7 ? 0 : SLAB_PTS, BUDGET);
-        if (ws.dbg_follow_stop == 7) return 0;
-        const long long t1 = timing ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        if (timing) atomicMax(reinterpret_cast<unsigned long long*>(ws.dbg + 4 * 8000), (unsigned long long)(t1 - t0));
+        const LeanTrace lt = trace_lean(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, slab, SLAB_PTS, BUDGET);
         if (lt.status == TRACE_OVERRUN) return 1;  // budget exhausted: a longer border
-        if (ws.dbg_follow_stop == 9) {  // instrumentation: longest / total border length seen by tier 2
-            atomicMax(ws.counters + 20, lt.steps);
-            atomicAdd(ws.counters + 21, lt.steps);
-            atomicAdd(ws.counters + 22, 1);
-        }
         if (lt.status != TRACE_OK || lt.npts < 4) return false;
         if (lt.npts <= SLAB_PTS) {
-            if (ws.dbg_follow_stop == 1 || ws.dbg_follow_stop == 3) return false;
             *slab_npts = lt.npts;   // finished by the whole wave, one border at a time (follow_kernel)
             return 3;
         }
@@ -306,7 +295,7 @@ __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand
     // budget exhausted: next tier -- or, from tier 1, straight to the wave tier when the border barely turned in 96 steps
     // (image-sized straight borders would only burn tier 2's whole budget before getting there anyway)
     if (st.status == TRACE_OVERRUN) return (TIER == 1 && st.npts <= 2) ? 2 : 1;
-    if (!worth_approximating(st) || ws.dbg_follow_stop == 1) return false;
+    if (!worth_approximating(st)) return false;
     const int need = 2 * st.npts + 2 * (st.npts + 2);
     const long long off = atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
     if (off + need > ws.cap_pool_ints) {
@@ -315,7 +304,6 @@ __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand
     }
     int* pts = ws.pool + off;
     trace_border<true, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, pts, st.npts, BUDGET);
-    if (ws.dbg_follow_stop == 2) return false;
     approximate_and_emit<CROP>(ws, c, pl, pts, st.npts, st.perimeter, reinterpret_cast<DpSlice*>(pts + 2 * st.npts));
     return false;
 }
@@ -331,14 +319,11 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
     int* ticket = ws.counters + (TIER == 1 ? (CROP ? CNT_TICKET_C : CNT_TICKET_F) : (CROP ? CNT_TICKET_MC : CNT_TICKET_MF));
     int* n_long = ws.counters + (TIER == 1 ? (CROP ? CNT_MID_C : CNT_MID_F) : (CROP ? CNT_LONG_C : CNT_LONG_F));
     const int lane = threadIdx.x & 63;
-    const long long t_begin = ws.dbg_follow_stop == 8 ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    int n_tickets = 0;
     for (;;) {
         int base = 0;
         if (lane == 0) base = atomicAdd(ticket, 64);
         base = __shfl(base, 0);
         if (base >= n) break;
-        n_tickets++;
         const int idx = base + lane;
         StartCand c;
         c.roi = 0; c.pos = 0; c.is_hole = 0;
@@ -386,16 +371,6 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
                 if (slot < ws.cap_long) list[slot] = c;
                 else atomicOr(ws.counters + CNT_ERR, ERR_CAND_OVERFLOW);
             }
-        }
-    }
-    if (ws.dbg_follow_stop == 8 && TIER == 2 && lane == 0) {
-        const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (w < 8192) {
-            long long* d = ws.dbg + (size_t)(w + (CROP ? 4096 : 0)) * 4;
-            d[0] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
-            d[1] = n_tickets;
-            d[2] = n;
-            d[3] = t_begin;
         }
     }
 }
@@ -590,9 +565,8 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
             if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TRACE_OVERRUN);
             continue;
         }
-        if (lt.status != TRACE_OK || lt.npts < 4 || ws.dbg_follow_stop == 1) continue;
+        if (lt.status != TRACE_OK || lt.npts < 4) continue;
         if (lt.npts <= LDS_PTS) {   // the usual case: points are in LDS, no second follow
-            if (ws.dbg_follow_stop == 4) continue;
             // all lanes run statistics + approximation on the LDS points (same addresses: broadcast reads, identical
             // stack writes), lane 0 publishes
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -616,7 +590,6 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
         }
         int* pts = ws.pool + off;
         trace_lean_tiled(t, c.pos, c.is_hole, pts, st.npts, max_steps);
-        if (ws.dbg_follow_stop == 2) continue;
         if (lane == 0) {
             __threadfence_block();
             const TraceStats sp = stats_of_points(pts, st.npts);

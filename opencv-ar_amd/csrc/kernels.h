@@ -49,7 +49,6 @@ struct Workspace {
     // per batch geometry
     int W, H, sw, sh, ns, n_frames, n_templates;   // ns: row stride of a neighbour-mask plane = sw rounded up to 4
     int mid_steps, long_blocks;  // tuning (env OCVAR_MID_STEPS / OCVAR_LONG_BLOCKS): tier-2 step budget, tier-3 grid
-    int dbg_follow_stop;  // experiments only (env OCVAR_DBG_FOLLOW_STOP): 1 = stop after the first follow, 2 = after the second
     int frame_strips, frame_chunks, frame_chunk_rows;  // binarise work decomposition of a frame
     // device buffers
     uint8_t* gray;          // [B][H][W]
@@ -84,7 +83,6 @@ struct Workspace {
     TemplateRec* templates; // [MAXT]
     CameraRec* camera;
     int* counters;          // [CNT_COUNT]
-    long long* dbg;         // [8192][4] per-wave instrumentation (cycles, steps, tickets, kernel tag); experiments only
 };
 
 // launchers (each enqueues on `stream`, no synchronisation)

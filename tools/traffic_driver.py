@@ -1,0 +1,18 @@
+"""Driver profiled by tools/collect_traffic.py: one calibration copy + a few 1080p batches."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import helpers as H
+import opencv_ar_amd as oa
+B, CAL = 64, 1 << 28
+cfg = H.synth_config(3)
+frames = np.stack([H.synth_frame(cfg, i)[0] for i in range(16)] * (B // 16))
+tpls, cam = H.oracle_templates(), H.oracle_camera(cfg.width, cfg.height)
+det = oa.Detector(cfg.width, cfg.height, max_batch=B)
+det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls]); det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+assert oa.hip_lib().ocvar_hip_debug_calibrate(det._ctx, CAL) == 0
+d = torch.from_numpy(frames).cuda()
+for _ in range(4):
+    det.detect_device(d.data_ptr(), cfg.width, cfg.height, B)
+print("traffic_driver: batch", B, "calibration bytes", CAL, "crop pixels/frame", det.counters()[4] / B)
