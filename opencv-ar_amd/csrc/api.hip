@@ -92,6 +92,7 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     if ((rc = dev_alloc(c, &w.cands_crop, (size_t)w.cap_crop_cands))) return rc;
     if ((rc = dev_alloc(c, &w.pool, (size_t)w.cap_pool_ints))) return rc;
     if ((rc = dev_alloc(c, &w.slab, (size_t)MID_BLOCKS * 256 * (4 * SLAB_PTS + 4)))) return rc;
+    if ((rc = dev_alloc(c, &w.slab3, (size_t)LONG_BLOCKS_MAX * 4 * (4 * SLAB3_PTS + 4)))) return rc;
     w.cap_long = (int)std::min<size_t>(B * 4096, (size_t)1 << 28);
     if ((rc = dev_alloc(c, &w.mid_frame, (size_t)w.cap_long))) return rc;
     if ((rc = dev_alloc(c, &w.mid_crop, (size_t)w.cap_long))) return rc;
@@ -162,6 +163,21 @@ extern "C" int ocvar_hip_set_camera(OcvarHip* c, const OcvarCamera* cam) {
     return OCVAR_OK;
 }
 
+// OCVAR_TRACE_LAUNCHES=1: wait after every launch and name it on stderr (locating a faulting or hanging kernel)
+static bool trace_launches() {
+    static const bool on = std::getenv("OCVAR_TRACE_LAUNCHES") != nullptr;
+    return on;
+}
+#define TRACE_LAUNCH(name)                                                               \
+    do {                                                                                 \
+        if (trace_launches()) {                                                          \
+            std::fprintf(stderr, "ocvar: %s ...", name);                                 \
+            std::fflush(stderr);                                                         \
+            hipError_t e_ = hipStreamSynchronize(s);                                     \
+            std::fprintf(stderr, " %s\n", e_ == hipSuccess ? "ok" : hipGetErrorString(e_)); \
+        }                                                                                \
+    } while (0)
+
 static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride, int n_frames,
                         int grey_in_place, const OcvarMarker* prev, const int* prev_counts, hipStream_t s, int stages) {
     Workspace& w = c->ws;
@@ -180,7 +196,8 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     w.ns = (w.sw + 15) & ~15;
     w.n_frames = n_frames;
     w.mid_steps = std::getenv("OCVAR_MID_STEPS") ? std::atoi(std::getenv("OCVAR_MID_STEPS")) : MID_STEPS;
-    w.long_blocks = std::getenv("OCVAR_LONG_BLOCKS") ? std::atoi(std::getenv("OCVAR_LONG_BLOCKS")) : 1024;
+    w.long_blocks = std::getenv("OCVAR_LONG_BLOCKS") ? std::atoi(std::getenv("OCVAR_LONG_BLOCKS")) : LONG_BLOCKS_MAX;
+    if (w.long_blocks < 1 || w.long_blocks > LONG_BLOCKS_MAX) w.long_blocks = LONG_BLOCKS_MAX;
     w.frame_strips = (w.sw + MARCH_STRIP - 1) / MARCH_STRIP;
     {   // rows per binarise work unit: about 128, even, chunks of equal size
         int chunks = (w.sh + 64) / 128;
@@ -200,27 +217,44 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     }
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     launch_binarise_frames(w, d_bgr, row_stride, frame_stride, grey_in_place, s);
+    TRACE_LAUNCH("binarise_frames");
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     launch_follow_frames(w, s);
+    TRACE_LAUNCH("follow tier 1 (frames)");
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
     launch_follow_mid_frames(w, s);
+    TRACE_LAUNCH("follow tier 2 (frames)");
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     launch_follow_long_frames(w, s);
+    TRACE_LAUNCH("follow tier 3 (frames)");
     HIP_TRY(c, hipEventRecord(c->ev[4], s));
     launch_order_and_crops(w, s);
+    TRACE_LAUNCH("order_and_crops");
     HIP_TRY(c, hipEventRecord(c->ev[5], s));
     if (stages > 2) {
         launch_binarise_crops(w, s);
+        TRACE_LAUNCH("binarise_crops");
+    TRACE_LAUNCH("binarise_crops");
         HIP_TRY(c, hipEventRecord(c->ev[6], s));
         launch_follow_crops(w, s);
+        TRACE_LAUNCH("follow tier 1 (crops)");
+    TRACE_LAUNCH("follow tier 1 (crops)");
         HIP_TRY(c, hipEventRecord(c->ev[7], s));
         launch_follow_mid_crops(w, s);
+        TRACE_LAUNCH("follow tier 2 (crops)");
+    TRACE_LAUNCH("follow tier 2 (crops)");
         HIP_TRY(c, hipEventRecord(c->ev[8], s));
         launch_follow_long_crops(w, s);
+        TRACE_LAUNCH("follow tier 3 (crops)");
+    TRACE_LAUNCH("follow tier 3 (crops)");
         HIP_TRY(c, hipEventRecord(c->ev[9], s));
         launch_decode(w, s);
+        TRACE_LAUNCH("decode");
+    TRACE_LAUNCH("decode");
         HIP_TRY(c, hipEventRecord(c->ev[10], s));
         launch_finalise(w, s);
+        TRACE_LAUNCH("finalise");
+    TRACE_LAUNCH("finalise");
         HIP_TRY(c, hipEventRecord(c->ev[11], s));
         HIP_TRY(c, hipMemcpyAsync(c->h_counts, w.n_markers, n_frames * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipMemcpyAsync(c->h_markers, w.markers, (size_t)n_frames * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToHost, s));

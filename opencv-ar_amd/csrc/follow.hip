@@ -539,12 +539,14 @@ __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* 
 template <bool CROP>
 __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
     __shared__ __attribute__((aligned(16))) uint8_t tiles[4][TILE * TILE];
-    __shared__ int lpts[4][4 * LDS_PTS + 4];   // per wave: points, then the approximation's stack
+    __shared__ DpSlice wstack[4][WAVE_STACK];
     const StartCand* longs = CROP ? ws.long_crop : ws.long_frame;
     int n = ws.counters[CROP ? CNT_LONG_C : CNT_LONG_F];
     if (n > ws.cap_long) n = ws.cap_long;
     int* ticket = ws.counters + (CROP ? CNT_TICKET_LC : CNT_TICKET_LF);
     const int lane = threadIdx.x & 63;
+    // this wave's point + stack space in global memory (points are written by lane 0 while all lanes walk)
+    int* slab = ws.slab3 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (4 * SLAB3_PTS + 4);
     for (;;) {
         int idx = 0;
         if (lane == 0) idx = atomicAdd(ticket, 1);
@@ -558,43 +560,22 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
         t.ns = pl.ns;
         t.sh = pl.sh;
         t.tx0 = t.ty0 = -(1 << 28);
-        const int max_steps = 4 * pl.plane + 16;
-        int* lp = lpts[threadIdx.x >> 6];
-        const LeanTrace lt = trace_lean_tiled(t, c.pos, c.is_hole, lp, LDS_PTS, max_steps);
+        const LeanTrace lt = trace_lean_tiled(t, c.pos, c.is_hole, slab, SLAB3_PTS, 4 * pl.plane + 16);
         if (lt.status == TRACE_OVERRUN) {
             if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TRACE_OVERRUN);
             continue;
         }
         if (lt.status != TRACE_OK || lt.npts < 4) continue;
-        if (lt.npts <= LDS_PTS) {   // the usual case: points are in LDS, no second follow
-            // all lanes run statistics + approximation on the LDS points (same addresses: broadcast reads, identical
-            // stack writes), lane 0 publishes
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            if (!wave_finish_border<CROP>(ws, c, pl, lp, lt.npts, reinterpret_cast<DpSlice*>(lp + 2 * LDS_PTS))) {
-                const TraceStats sp = stats_of_points(lp, lt.npts);
-                if (worth_approximating(sp))
-                    approximate_and_emit<CROP>(ws, c, pl, lp, sp.npts, sp.perimeter, reinterpret_cast<DpSlice*>(lp + 2 * LDS_PTS), lane == 0);
-            }
-            continue;
-        }
-        // more points than the LDS buffer holds: store them in the pool with a second follow
-        TraceStats st;
-        st.npts = lt.npts;
-        const int need = 2 * st.npts + 2 * (st.npts + 2);
-        long long off = 0;
-        if (lane == 0) off = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
-        off = (long long)(unsigned)__shfl((int)(off & 0xffffffffll), 0) | ((long long)__shfl((int)(off >> 32), 0) << 32);
-        if (off + need > ws.cap_pool_ints) {
+        if (lt.npts > SLAB3_PTS) {   // more contour points than the slab holds: report, never truncate silently
             if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_POOL_OVERFLOW);
             continue;
         }
-        int* pts = ws.pool + off;
-        trace_lean_tiled(t, c.pos, c.is_hole, pts, st.npts, max_steps);
-        if (lane == 0) {
-            __threadfence_block();
-            const TraceStats sp = stats_of_points(pts, st.npts);
+        if (!wave_finish_border<CROP>(ws, c, pl, slab, lt.npts, wstack[threadIdx.x >> 6])) {
+            // deeper recursion than the LDS stack holds: every lane runs the sequential routine on the same data
+            // (stack behind the points in the slab: identical writes), lane 0 publishes
+            const TraceStats sp = stats_of_points(slab, lt.npts);
             if (worth_approximating(sp))
-                approximate_and_emit<CROP>(ws, c, pl, pts, sp.npts, sp.perimeter, reinterpret_cast<DpSlice*>(pts + 2 * st.npts));
+                approximate_and_emit<CROP>(ws, c, pl, slab, lt.npts, sp.perimeter, reinterpret_cast<DpSlice*>(slab + 2 * SLAB3_PTS), lane == 0);
         }
     }
 }

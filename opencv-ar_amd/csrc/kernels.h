@@ -19,7 +19,8 @@ constexpr int SHORT_STEPS = 96;            // step budget of follower tier 1 (ev
 constexpr int MID_STEPS = 1536;            // step budget of tier 2 (borders that outlived tier 1, one lane each); the rest: tier 3, one wave each
 constexpr int SLAB_PTS = 1024;             // points a tier-2 lane can keep in its private slab (no second follow needed below that)
 constexpr int MID_BLOCKS = 512;            // tier-2 grid (x256 threads, one slab each)
-constexpr int LDS_PTS = 512;               // points a tier-3 wave can keep in LDS
+constexpr int SLAB3_PTS = 8192;            // points a tier-3 wave can keep in its slab
+constexpr int LONG_BLOCKS_MAX = 1024;      // tier-3 grid limit (x4 waves, one slab each)
 constexpr int TILE = 64;                   // side of the LDS tile the wave-per-border follower walks in             // backward look of an outer start before it follows its border
 
 // error bits accumulated in Workspace::err[0]
@@ -63,6 +64,7 @@ struct Workspace {
     int cap_long;
     int* pool;              // points + DP stacks
     int* slab;              // [MID_BLOCKS*256][4*SLAB_PTS+4] private point + stack space of the tier-2 lanes
+    int* slab3;             // [LONG_BLOCKS_MAX*4][4*SLAB3_PTS+4] point + stack space of the tier-3 waves
     QuadRec* quads_frame;   // [B][MAXQ] unordered
     int* n_quads_frame;     // [B]
     float* squares;         // [B][MAXQ][8] ordered, after tracking

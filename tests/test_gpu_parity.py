@@ -186,3 +186,50 @@ def test_round_trip_properties_full_size(oa):
             assert dist.max() < 12.0
             hits += 1
     assert hits >= 3
+
+
+def _sawtooth_frame(w, h, tooth, shapes):
+    """White frame with dark rectangles whose edges are sawtoothed: borders with thousands of CHAIN_APPROX_SIMPLE points."""
+    img = np.full((h, w), 220, np.uint8)
+    for (x0, y0, x1, y1) in shapes:
+        img[y0:y1, x0:x1] = 20
+        for x in range(x0, x1, 2 * tooth):          # teeth along the top and bottom edges
+            img[y0 - tooth:y0, x:x + tooth] = 20
+            img[y1:y1 + tooth, x + tooth:x + 2 * tooth] = 20
+        for y in range(y0, y1, 2 * tooth):          # and along the left and right edges
+            img[y:y + tooth, x0 - tooth:x0] = 20
+            img[y + tooth:y + 2 * tooth, x1:x1 + tooth] = 20
+    return np.repeat(img[:, :, None], 3, axis=2)
+
+
+def test_borders_with_thousands_of_points(oa):
+    """Long, point-rich borders go through the follower's upper tiers (lane slabs, wave slabs); results must not
+    depend on which tier handled a border."""
+    w, h = 1280, 960
+    cfg = H.synth_config(2, width=w, height=h)
+    det, tpls, cam = make_detector(oa, cfg, ["2x2-01"], 2)
+    frames = np.stack([_sawtooth_frame(w, h, 6, [(100, 100, 700, 500), (800, 150, 1200, 900), (150, 600, 650, 880)]),
+                       _sawtooth_frame(w, h, 4, [(60, 60, 1220, 900)])])
+    markers, counts = det.detect_host(frames.copy())
+    for f in range(2):
+        check_frame(det, f, frames[f], tpls, cam, markers, counts)
+    # the square finder alone, on a crop-sized image cut out of the first frame
+    crop = np.ascontiguousarray(frames[0][80:540, 80:740, 0])
+    ref = H.oracle_find_squares(crop)
+    got, n = det.find_squares(crop)
+    assert n == len(ref) and np.array_equal(got, ref)
+
+
+def test_capacity_overflow_is_loud_not_wrong(oa):
+    """A border with more points than any follower tier can hold must either be handled exactly or make the call
+    fail with OCVAR_E_CAPACITY -- never a silently different result."""
+    w, h = 3840, 2160
+    cfg = H.synth_config(2, width=w, height=h)
+    det, tpls, cam = make_detector(oa, cfg, ["2x2-01"], 1)
+    frame = _sawtooth_frame(w, h, 4, [(40, 40, 3800, 2120)])
+    try:
+        markers, counts = det.detect_host(frame[None].copy())
+    except oa.OcvarError as e:
+        assert "-4" in str(e) or "overflow" in str(e)
+        return
+    check_frame(det, 0, frame, tpls, cam, markers, counts)

@@ -13,6 +13,9 @@ tpls = H.oracle_templates(names); cam = H.oracle_camera(cfg.width, cfg.height)
 print("creating", flush=True)
 det = oa.Detector(cfg.width, cfg.height, max_batch=1)
 det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls]); det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+print("find_squares (frame pass only)", flush=True)
+q, nq = det.find_squares(np.ascontiguousarray(frame[..., 0]))
+print("frame pass ok", nq, det.stage_ms(), flush=True)
 print("detecting", flush=True)
 t0 = time.time()
 m, c = det.detect_host(frame[None].copy())
