@@ -234,27 +234,21 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     if (stages > 2) {
         launch_binarise_crops(w, s);
         TRACE_LAUNCH("binarise_crops");
-    TRACE_LAUNCH("binarise_crops");
         HIP_TRY(c, hipEventRecord(c->ev[6], s));
         launch_follow_crops(w, s);
         TRACE_LAUNCH("follow tier 1 (crops)");
-    TRACE_LAUNCH("follow tier 1 (crops)");
         HIP_TRY(c, hipEventRecord(c->ev[7], s));
         launch_follow_mid_crops(w, s);
         TRACE_LAUNCH("follow tier 2 (crops)");
-    TRACE_LAUNCH("follow tier 2 (crops)");
         HIP_TRY(c, hipEventRecord(c->ev[8], s));
         launch_follow_long_crops(w, s);
         TRACE_LAUNCH("follow tier 3 (crops)");
-    TRACE_LAUNCH("follow tier 3 (crops)");
         HIP_TRY(c, hipEventRecord(c->ev[9], s));
         launch_decode(w, s);
         TRACE_LAUNCH("decode");
-    TRACE_LAUNCH("decode");
         HIP_TRY(c, hipEventRecord(c->ev[10], s));
         launch_finalise(w, s);
         TRACE_LAUNCH("finalise");
-    TRACE_LAUNCH("finalise");
         HIP_TRY(c, hipEventRecord(c->ev[11], s));
         HIP_TRY(c, hipMemcpyAsync(c->h_counts, w.n_markers, n_frames * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipMemcpyAsync(c->h_markers, w.markers, (size_t)n_frames * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToHost, s));

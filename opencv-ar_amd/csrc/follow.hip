@@ -11,6 +11,30 @@
 
 namespace ocvar {
 
+// Wave-uniform values.  The wave-cooperative code below (tier-2 finishing, tier 3) keeps all 64 lanes on the same
+// border, so its control flow is uniform by construction -- but the compiler only knows that for values it can prove
+// uniform.  For a value that lives in a VGPR it builds EXEC-masked "divergent" control flow instead, and it may then
+// place a cross-lane operation (ds_bpermute, DPP) where some lanes are masked off; a loop with `continue` around such
+// code hung on hardware.  Passing every control value through v_readfirstlane makes the branches scalar (and moves
+// the walker's state to SGPRs / the scalar ALU).
+//
+// One more trap of the same family: `if (lane == 0) ...` as the last statement of a loop body followed by
+// `if (lane == 0) ticket = atomicAdd(...)` as the first statement of the next iteration.  The optimiser threads the two
+// identical predicates through the back-edge and rotates the loop so that lanes 1..63 iterate WITHOUT lane 0 (their
+// ticket is the phi's initial 0, v_readfirstlane then reads lane 1): those lanes re-run task 0 forever.  The ticket
+// fetch therefore tests an opaque copy of the lane id (ticket_lane()) that the compiler cannot relate to `lane`.
+__device__ __forceinline__ int ticket_lane() {
+    int l = (int)(threadIdx.x & 63);
+    asm volatile("" : "+v"(l));
+    return l;
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long uni(unsigned long long v) {
+    return ((unsigned long long)uni((unsigned)(v >> 32)) << 32) | uni((unsigned)v);
+}
+__device__ __forceinline__ double uni(double v) { return __longlong_as_double((long long)uni((unsigned long long)__double_as_longlong(v))); }
+
 // geometry of the ROI a start belongs to
 struct PlaneRef {
     const uint8_t* nbr;
@@ -84,17 +108,17 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
         const unsigned long long o = ((unsigned long long)hi << 32) | lo;
         v = o > v ? o : v;
     }
-    return v;
+    return uni(v);
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
-    return v;
+    return uni(v);
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
-    return v;
+    return uni(v);
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -103,7 +127,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
         const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)b, off), hi = (unsigned)__shfl_xor((int)(unsigned)((unsigned long long)b >> 32), off);
         v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     }
-    return v;
+    return uni(v);
 }
 
 __device__ TraceStats wave_stats_of_points(const int* pts, int n) {
@@ -145,8 +169,8 @@ __device__ int wave_approx_poly_dp(const int* src, int count, double parameter, 
     int pos = 0;
     for (int it = 0; it < 3; it++) {
         pos = (pos + right.start) % count;
-        sx = src[2 * pos];
-        sy = src[2 * pos + 1];
+        sx = uni(src[2 * pos]);
+        sy = uni(src[2 * pos + 1]);
         unsigned long long best = 0;
         for (int j = 1 + lane; j < count; j += 64) {
             int q = pos + j;
@@ -180,12 +204,14 @@ __device__ int wave_approx_poly_dp(const int* src, int count, double parameter, 
     for (int guard = 4 * count + 16; top > 0;) {
         if (--guard < 0) return DP_MAX_OUT + 1;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        slice = stack[--top];
+        --top;
+        slice.start = uni(stack[top].start);
+        slice.end = uni(stack[top].end);
         const int e = slice.end >= count ? slice.end - count : slice.end;
         const int b = slice.start >= count ? slice.start - count : slice.start;
-        const int ex = src[2 * e], ey = src[2 * e + 1];
-        sx = src[2 * b];
-        sy = src[2 * b + 1];
+        const int ex = uni(src[2 * e]), ey = uni(src[2 * e + 1]);
+        sx = uni(src[2 * b]);
+        sy = uni(src[2 * b + 1]);
         if (slice.end > slice.start + 1) {
             const int dx = ex - sx, dy = ey - sy;
             unsigned long long best = 0;
@@ -321,8 +347,8 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
     const int lane = threadIdx.x & 63;
     for (;;) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(ticket, 64);
-        base = __shfl(base, 0);
+        if (ticket_lane() == 0) base = atomicAdd(ticket, 64);
+        base = uni(base);
         if (base >= n) break;
         const int idx = base + lane;
         StartCand c;
@@ -335,17 +361,18 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
         if (TIER == 2) {
             // borders stored in the lanes' slabs: statistics, approximation and filter by the whole wave, one at a time
             unsigned long long todo = __ballot(route == 3);
+            if (todo) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // each lane stored its own slab; now every lane reads them
             while (todo) {
                 const int L = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 StartCand cl;
-                cl.roi = __shfl(c.roi, L);
-                cl.pos = __shfl(c.pos, L);
-                cl.is_hole = __shfl(c.is_hole, L);
-                const int nl = __shfl(slab_npts, L);
-                const int* slab = ws.slab + ((size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63) + L) * (4 * SLAB_PTS + 4);
+                cl.roi = __builtin_amdgcn_readlane(c.roi, L);
+                cl.pos = __builtin_amdgcn_readlane(c.pos, L);
+                cl.is_hole = __builtin_amdgcn_readlane(c.is_hole, L);
+                const int nl = __builtin_amdgcn_readlane(slab_npts, L);
+                const int* slab = ws.slab + ((size_t)blockIdx.x * blockDim.x + uni((int)(threadIdx.x & ~63u)) + L) * (4 * SLAB_PTS + 4);
                 const PlaneRef pl = plane_of<CROP>(ws, cl.roi);
-                if (!wave_finish_border<CROP>(ws, cl, pl, slab, nl, wstack[threadIdx.x >> 6])) {
+                if (!wave_finish_border<CROP>(ws, cl, pl, slab, nl, wstack[uni((int)(threadIdx.x >> 6))])) {
                     // deeper recursion than the LDS stack holds: every lane runs the sequential routine on the same data
                     // (stack in the owner's slab: identical writes), lane 0 publishes
                     const TraceStats sp = stats_of_points(slab, nl);
@@ -385,7 +412,7 @@ struct TileCache {
     uint8_t* lds;          // TILE*TILE bytes of this wave
     const uint8_t* nbr;
     int ns, sh;            // ns is a multiple of 16, the plane base is 16-byte aligned
-    int tx0, ty0;          // window origin (tx0 multiple of 16, may be negative)
+    int tx0, ty0;          // window origin (tx0 multiple of 16, may be negative); wave-uniform
 };
 
 // (bx,by): direction of travel; the window is pushed ahead so that a straight run re-centres as rarely as possible
@@ -407,11 +434,13 @@ __device__ __forceinline__ void tile_load(TileCache& t, int x, int y, int bx = 0
 
 __device__ __forceinline__ unsigned tile_get(TileCache& t, int x, int y) {
     if ((unsigned)(x - t.tx0) >= (unsigned)TILE || (unsigned)(y - t.ty0) >= (unsigned)TILE) tile_load(t, x, y);
-    return t.lds[(y - t.ty0) * TILE + (x - t.tx0)];
+    return uni((unsigned)t.lds[(y - t.ty0) * TILE + (x - t.tx0)]);
 }
 
-// Lean follower on the tile cache (wave-uniform: all lanes walk the same border).  Points go to `out` (LDS or
-// global, written by lane 0) up to max_pts; statistics are recomputed from the points afterwards.
+// Lean follower on the tile cache.  All 64 lanes walk the same border and the walker's state (position, direction,
+// mask, counters) is wave-uniform -- kept in SGPRs, stepped by the scalar ALU, branches scalar.  Corner points are
+// parked in a lane of (hx,hy) (lane = point index mod 64) and written 64 at a time, one coalesced 512-byte store,
+// up to max_pts (the count keeps running beyond it); statistics are recomputed from the points afterwards.
 __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* out, int max_pts, int max_steps) {
     const int lane = threadIdx.x & 63;
     LeanTrace r;
@@ -433,6 +462,8 @@ __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* 
     int prev_s = s ^ 4;
     int straight = 0;  // consecutive straight steps through identical masks (a long run is likely once this is 2)
     int step = 0;
+    int hx = 0, hy = 0;
+    int2* out2 = reinterpret_cast<int2*>(out);
     for (;; step++) {
         if (step >= max_steps) {
             r.status = TRACE_OVERRUN;
@@ -448,9 +479,11 @@ __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* 
             break;
         }
         if (e != prev_s) {
-            if (r.npts < max_pts && lane == 0) {
-                out[2 * r.npts] = x;
-                out[2 * r.npts + 1] = y;
+            if (r.npts < max_pts) {
+                const int slot = r.npts & 63;
+                hx = lane == slot ? x : hx;   // v_cndmask: no EXEC change
+                hy = lane == slot ? y : hy;
+                if (slot == 63) out2[r.npts - 63 + lane] = make_int2(hx, hy);
             }
             r.npts++;
             prev_s = e;
@@ -480,7 +513,8 @@ __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* 
                     const bool in_tile = (unsigned)(qx - t.tx0) < (unsigned)TILE && (unsigned)(qy - t.ty0) < (unsigned)TILE;
                     const unsigned mq = in_tile ? t.lds[(qy - t.ty0) * TILE + (qx - t.tx0)] : 256u;
                     const bool closes = qx == x0 && qy == y0 && qx - ddx == x1 && qy - ddy == y1;
-                    const unsigned long long stop = __ballot(closes || mq != m);
+                    const unsigned long long close_mask = __ballot(closes);
+                    const unsigned long long stop = close_mask | __ballot(mq != m);
                     const int k = stop ? __ffsll((long long)stop) - 1 : 64;   // pixels (x,y)+1..k carry mask m
                     // scan positions are monotonic along a line: the two ends decide
                     const int pa = y * ns + x, pb = (y + k * ddy) * ns + x + k * ddx;
@@ -498,12 +532,11 @@ __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* 
                         break;
                     }
                     if (k == 64) continue;
-                    const int stop_closes = __shfl((int)closes, k);
-                    const unsigned stop_m = (unsigned)__shfl((int)mq, k);
-                    if (stop_closes) {
+                    if ((close_mask >> k) & 1ull) {
                         closed = true;
                         break;
                     }
+                    const unsigned stop_m = (unsigned)__builtin_amdgcn_readlane((int)mq, k);
                     if (stop_m == 256u) {  // end of the window: re-centre ahead and keep running
                         if ((unsigned)(x + ddx) >= (unsigned)ns || (unsigned)(y + ddy) >= (unsigned)t.sh) {
                             r.status = TRACE_OVERRUN;
@@ -532,6 +565,11 @@ __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* 
         m = m4;
         s = e ^ 4;
     }
+    if (r.status == TRACE_OK) {   // the points still parked in lanes
+        const int stored = r.npts < max_pts ? r.npts : max_pts;
+        const int rem = stored & 63;
+        if (lane < rem) out2[stored - rem + lane] = make_int2(hx, hy);
+    }
     r.steps = step;
     return r;
 }
@@ -545,37 +583,42 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
     if (n > ws.cap_long) n = ws.cap_long;
     int* ticket = ws.counters + (CROP ? CNT_TICKET_LC : CNT_TICKET_LF);
     const int lane = threadIdx.x & 63;
-    // this wave's point + stack space in global memory (points are written by lane 0 while all lanes walk)
-    int* slab = ws.slab3 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (4 * SLAB3_PTS + 4);
+    const int wave = uni((int)(threadIdx.x >> 6));
+    // this wave's point + stack space in global memory
+    int* slab = ws.slab3 + ((size_t)blockIdx.x * 4 + wave) * (4 * SLAB3_PTS + 4);
     for (;;) {
         int idx = 0;
-        if (lane == 0) idx = atomicAdd(ticket, 1);
-        idx = __shfl(idx, 0);
+        if (ticket_lane() == 0) idx = atomicAdd(ticket, 1);
+        idx = uni(idx);
         if (idx >= n) break;
-        const StartCand c = longs[idx];
+        StartCand c = longs[idx];
+        c.roi = uni(c.roi);
+        c.pos = uni(c.pos);
+        c.is_hole = uni(c.is_hole);
         const PlaneRef pl = plane_of<CROP>(ws, c.roi);
         TileCache t;
-        t.lds = tiles[threadIdx.x >> 6];
+        t.lds = tiles[wave];
         t.nbr = pl.nbr;
-        t.ns = pl.ns;
-        t.sh = pl.sh;
+        t.ns = uni(pl.ns);
+        t.sh = uni(pl.sh);
         t.tx0 = t.ty0 = -(1 << 28);
-        const LeanTrace lt = trace_lean_tiled(t, c.pos, c.is_hole, slab, SLAB3_PTS, 4 * pl.plane + 16);
+        const LeanTrace lt = trace_lean_tiled(t, c.pos, c.is_hole, slab, SLAB3_PTS, 4 * uni(pl.plane) + 16);
+        // (no `continue` below: one back-edge, scalar conditions -- see uni())
         if (lt.status == TRACE_OVERRUN) {
             if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TRACE_OVERRUN);
-            continue;
-        }
-        if (lt.status != TRACE_OK || lt.npts < 4) continue;
-        if (lt.npts > SLAB3_PTS) {   // more contour points than the slab holds: report, never truncate silently
-            if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_POOL_OVERFLOW);
-            continue;
-        }
-        if (!wave_finish_border<CROP>(ws, c, pl, slab, lt.npts, wstack[threadIdx.x >> 6])) {
-            // deeper recursion than the LDS stack holds: every lane runs the sequential routine on the same data
-            // (stack behind the points in the slab: identical writes), lane 0 publishes
-            const TraceStats sp = stats_of_points(slab, lt.npts);
-            if (worth_approximating(sp))
-                approximate_and_emit<CROP>(ws, c, pl, slab, lt.npts, sp.perimeter, reinterpret_cast<DpSlice*>(slab + 2 * SLAB3_PTS), lane == 0);
+        } else if (lt.status == TRACE_OK && lt.npts >= 4) {
+            if (lt.npts > SLAB3_PTS) {   // more contour points than the slab holds: report, never truncate silently
+                if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_POOL_OVERFLOW);
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // the points were stored by other lanes of this wave
+                if (!wave_finish_border<CROP>(ws, c, pl, slab, lt.npts, wstack[wave])) {
+                    // deeper recursion than the LDS stack holds: every lane runs the sequential routine on the same data
+                    // (stack behind the points in the slab: identical writes), lane 0 publishes
+                    const TraceStats sp = stats_of_points(slab, lt.npts);
+                    if (worth_approximating(sp))
+                        approximate_and_emit<CROP>(ws, c, pl, slab, lt.npts, sp.perimeter, reinterpret_cast<DpSlice*>(slab + 2 * SLAB3_PTS), lane == 0);
+                }
+            }
         }
     }
 }

@@ -230,3 +230,120 @@ extern "C" int emul_sizes(int* out) {
     out[0] = sizeof(TemplateRec); out[1] = sizeof(CameraRec); out[2] = sizeof(MarkerRec); out[3] = sizeof(Roi);
     return 4;
 }
+
+// ---- host emulation of follow.hip::trace_lean_tiled (tier 3): the wave's 64 lanes are a loop, LDS is an array ----
+namespace tiled_emul {
+constexpr int TILE = 64;
+struct TileCache {
+    uint8_t lds[TILE * TILE];
+    const uint8_t* nbr;
+    int ns, sh, tx0, ty0;
+    long long loads;
+};
+static void tile_load(TileCache& t, int x, int y, int bx = 0, int by = 0) {
+    t.tx0 = (x + 20 * bx - TILE / 2 + 8) & ~15;
+    t.ty0 = y + 28 * by - TILE / 2;
+    t.loads++;
+    for (int lane = 0; lane < 64; lane++) {
+        const int row = t.ty0 + lane;
+        for (int cch = 0; cch < TILE / 16; cch++) {
+            const int cx = t.tx0 + 16 * cch;
+            for (int b = 0; b < 16; b++) {
+                uint8_t v = 0;
+                if (row >= 0 && row < t.sh && cx >= 0 && cx + 16 <= t.ns) v = t.nbr[(long long)row * t.ns + cx + b];
+                t.lds[lane * TILE + 16 * cch + b] = v;
+            }
+        }
+    }
+}
+static unsigned tile_get(TileCache& t, int x, int y) {
+    if ((unsigned)(x - t.tx0) >= (unsigned)TILE || (unsigned)(y - t.ty0) >= (unsigned)TILE) tile_load(t, x, y);
+    return t.lds[(y - t.ty0) * TILE + (x - t.tx0)];
+}
+static LeanTrace trace(TileCache& t, int cpos, int is_hole, int* out, int max_pts, int max_steps) {
+    LeanTrace r;
+    r.status = TRACE_OK; r.npts = 0; r.steps = 0;
+    const int ns = t.ns;
+    const int i0 = cpos - is_hole;
+    const int x0 = i0 % ns, y0 = i0 / ns;
+    int x = x0, y = y0;
+    unsigned m = tile_get(t, x, y);
+    if (m == 0) { r.status = TRACE_SINGLE; r.npts = 1; return r; }
+    int s = first_cw(m, (is_hole ? 0 : 4) - 1);
+    const int x1 = x0 + step_dx(s), y1 = y0 + step_dy(s);
+    int prev_s = s ^ 4;
+    int straight = 0;
+    int step = 0;
+    for (;; step++) {
+        if (step >= max_steps) { r.status = TRACE_OVERRUN; break; }
+        const int from = (s + 1) & 7;
+        const int tz = __builtin_ctz(((m * 0x101u) >> from) & 0xffu);
+        const int e = (from + tz) & 7;
+        const unsigned passed = ((((1u << tz) - 1u) * 0x101u) << from) >> 8;
+        const int idx = y * ns + x;
+        if (((passed & 0x10u) && idx < cpos) || ((passed & 1u) && idx + 1 < cpos)) { r.status = TRACE_NOT_FIRST; break; }
+        if (e != prev_s) {
+            if (r.npts < max_pts) { out[2 * r.npts] = x; out[2 * r.npts + 1] = y; }
+            r.npts++;
+            prev_s = e;
+        }
+        const int ddx = step_dx(e), ddy = step_dy(e);
+        const int px = x, py = y;
+        x += ddx; y += ddy;
+        if (x == x0 && y == y0 && px == x1 && py == y1) break;
+        if ((unsigned)x >= (unsigned)ns || (unsigned)y >= (unsigned)t.sh) { r.status = TRACE_OVERRUN; break; }
+        unsigned m4 = tile_get(t, x, y);
+        if (m4 == 0) { r.status = TRACE_OVERRUN; break; }
+        if (e == (s ^ 4) && m4 == m) {
+            if (++straight >= 2) {
+                bool closed = false, bad = false;
+                for (long long spin = 0;; spin++) {
+                    if (spin > 100000000ll) { r.status = 77; bad = true; break; }   // emulation only: report a spin
+                    int k = 64, stop_closes = 0; unsigned stop_m = 0;
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int qx = x + (lane + 1) * ddx, qy = y + (lane + 1) * ddy;
+                        const bool in_tile = (unsigned)(qx - t.tx0) < (unsigned)TILE && (unsigned)(qy - t.ty0) < (unsigned)TILE;
+                        const unsigned mq = in_tile ? t.lds[(qy - t.ty0) * TILE + (qx - t.tx0)] : 256u;
+                        const bool closes = qx == x0 && qy == y0 && qx - ddx == x1 && qy - ddy == y1;
+                        if (closes || mq != m) { k = lane; stop_closes = closes; stop_m = mq; break; }
+                    }
+                    const int pa = y * ns + x, pb = (y + k * ddy) * ns + x + k * ddx;
+                    if (((passed & 0x10u) && (pa < cpos || pb < cpos)) || ((passed & 1u) && (pa + 1 < cpos || pb + 1 < cpos))) {
+                        r.status = TRACE_NOT_FIRST; bad = true; break;
+                    }
+                    x += k * ddx; y += k * ddy; step += k;
+                    if (step >= max_steps) { r.status = TRACE_OVERRUN; bad = true; break; }
+                    if (k == 64) continue;
+                    if (stop_closes) { closed = true; break; }
+                    if (stop_m == 256u) {
+                        if ((unsigned)(x + ddx) >= (unsigned)ns || (unsigned)(y + ddy) >= (unsigned)t.sh) { r.status = TRACE_OVERRUN; bad = true; break; }
+                        tile_load(t, x + ddx, y + ddy, ddx, ddy);
+                        continue;
+                    }
+                    x += ddx; y += ddy; step++;
+                    m4 = stop_m;
+                    break;
+                }
+                if (bad || closed) break;
+                if (m4 == 0) { r.status = TRACE_OVERRUN; break; }
+                straight = 0;
+            }
+        } else {
+            straight = 0;
+        }
+        m = m4;
+        s = e ^ 4;
+    }
+    r.steps = step;
+    return r;
+}
+}  // namespace tiled_emul
+
+// follows the border starting at cpos with the tier-3 emulation; returns status, fills npts/steps/loads
+extern "C" int emul_trace_tiled(const uint8_t* nbr, int ns, int sh, int cpos, int is_hole, int* out, int max_pts, int max_steps, int* info) {
+    tiled_emul::TileCache t;
+    t.nbr = nbr; t.ns = ns; t.sh = sh; t.tx0 = t.ty0 = -(1 << 28); t.loads = 0;
+    LeanTrace r = tiled_emul::trace(t, cpos, is_hole, out, max_pts, max_steps);
+    info[0] = r.npts; info[1] = r.steps; info[2] = (int)t.loads;
+    return r.status;
+}
