@@ -20,6 +20,11 @@ namespace ocvar {
 
 constexpr int SV = MARCH_STRIP;  // output columns per strip (lanes 4..59)
 
+// A value that is the same in all lanes of the wave, moved to an SGPR.  The work-unit index comes from threadIdx.x >> 6,
+// which the compiler must treat as per-lane: without this every row counter of the march lives in a VGPR, every loop
+// test is a VALU compare + EXEC mask, and every row address is 64-bit VALU arithmetic.
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
     while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
@@ -36,6 +41,8 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(unsigned v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ unsigned as_u32(us2 v) { return __builtin_bit_cast(unsigned, v); }
 __device__ __forceinline__ unsigned dot4(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+__device__ __forceinline__ unsigned dot2(us2 a, unsigned k, unsigned c) { return __builtin_amdgcn_udot2(a, as_us2(k), c, false); }
+constexpr unsigned K2(unsigned lo, unsigned hi) { return lo | (hi << 16); }
 __device__ __forceinline__ unsigned alignb(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 __device__ __forceinline__ unsigned byte_of(unsigned v, int j) { return (v >> (8 * j)) & 255u; }
 
@@ -54,26 +61,10 @@ struct MarchOut {
     int* err;
 };
 
-// Lookup of the 8-neighbour mask (+ start type) of the centre pixel of a 3x3 bit window:
-// index = row above (3 bits: x-1,x,x+1) | row << 3 | row below << 6.  Low byte: mask in follower direction
-// order E,NE,N,NW,W,SW,S,SE; bits 8..9: 1 = can start an outer border, 2 = can start a hole border.
-__device__ __forceinline__ void build_nbr_lut(unsigned short* lut) {
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) {
-        const unsigned a = i & 7, m = (i >> 3) & 7, b = i >> 6;
-        const unsigned nw = a & 1, n = (a >> 1) & 1, ne = (a >> 2) & 1, w = m & 1, c = (m >> 1) & 1, e = (m >> 2) & 1;
-        const unsigned sw_ = b & 1, s = (b >> 1) & 1, se = (b >> 2) & 1;
-        unsigned v = e | (ne << 1) | (n << 2) | (nw << 3) | (w << 4) | (sw_ << 5) | (s << 6) | (se << 7);
-        if (c && !(w | nw | n | ne)) v |= 1u << 8;   // can be the raster-first pixel of a component
-        else if (!c && w && n) v |= 2u << 8;         // can be the raster-first pixel of a hole
-        lut[i] = (unsigned short)v;
-    }
-    __syncthreads();
-}
-
 // One work unit: strip `strip` of an (sw x sh) ROI, output rows [Y0, Y1).
 template <bool BGR>
 __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int sh, int strip, int Y0, int Y1, const MarchOut& o,
-                           const unsigned short* lut, unsigned* stage) {
+                           unsigned* stage) {
     const int lane = threadIdx.x & 63;
     const int XS = strip * SV - 16;
     const int c0 = XS + 4 * lane;
@@ -97,6 +88,8 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     }
     unsigned colmask = 0;  // which of the lane's 4 columns lie inside cvFindContours' zeroed frame
     for (int j = 0; j < 4; j++) colmask |= (c0 + j >= 1 && c0 + j <= sw - 2) ? (1u << j) : 0u;
+    unsigned pxmask = 0;   // bit 8j: the lane's pixel j is an output pixel of this strip
+    for (int j = 0; j < 4; j++) pxmask |= (out_lane && c0 + j < sw) ? (1u << (8 * j)) : 0u;
 
     // Border starts are staged per wave in LDS and appended to the global list with ONE atomic per flush: a
     // single list counter only sustains ~90 atomics/us chip-wide, which one atomic per image row would exceed.
@@ -170,13 +163,10 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     unsigned ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0;  // horizontal pyrDown sums of the last 5 rows (a | b<<16)
     unsigned prevP = 0;                      // previous pyramid row for the bottom border
     unsigned rAe = 0, rAo = 0, rBe = 0, rBo = 0;   // up-sampled pyramid rows q-2, q-1: even columns (r0|r2<<16), odd (r1|r3<<16)
-    unsigned hh[7][4];                       // horizontal Gaussian sums of the last 7 (virtual) rows, newest last
-    unsigned ur0 = 0, ur1 = 0, ur2 = 0, ur3 = 0;  // pyrUp rows, newest last
+    unsigned we[7], wo[7];                   // the last 7 (virtual) pyrUp rows, newest last: even columns (u0|u2<<16), odd (u1|u3<<16)
 #pragma unroll
-    for (int k = 0; k < 7; k++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) hh[k][j] = 0;
-    unsigned binw = 0;                       // threshold bits of rows y-2, y-1, y: nibbles 0,1,2
+    for (int k = 0; k < 7; k++) we[k] = wo[k] = 0;
+    unsigned binw = 0;                       // threshold bits of rows y-2, y-1, y in bytes 0,1,2 (bits 1..4 of each)
 
     Raw nxt = fetch(v_first);
     for (int v = v_first; v <= v_last; v++) {
@@ -220,83 +210,92 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
             for (int par = 0; par < 2; par++) {
                 const int u = 2 * (q - 1) + par;
                 if (u < 0 || u >= sh) continue;
-                unsigned U4;
+                us2 Ue, Uo;   // pyrUp row u at the lane's even columns (c0, c0+2) and odd columns (c0+1, c0+3)
                 if (par == 0) {
-                    const us2 e = (as_us2(rAe) + as_us2(rBe) * (unsigned short)6 + as_us2(rCe) + (unsigned short)32) >> (unsigned short)6;
-                    const us2 od = (as_us2(rAo) + as_us2(rBo) * (unsigned short)6 + as_us2(rCo) + (unsigned short)32) >> (unsigned short)6;
-                    U4 = as_u32(e) | (as_u32(od) << 8);
+                    Ue = (as_us2(rAe) + as_us2(rBe) * (unsigned short)6 + as_us2(rCe) + (unsigned short)32) >> (unsigned short)6;
+                    Uo = (as_us2(rAo) + as_us2(rBo) * (unsigned short)6 + as_us2(rCo) + (unsigned short)32) >> (unsigned short)6;
                 } else {
-                    const us2 e = ((as_us2(rBe) + as_us2(rCe)) * (unsigned short)4 + (unsigned short)32) >> (unsigned short)6;
-                    const us2 od = ((as_us2(rBo) + as_us2(rCo)) * (unsigned short)4 + (unsigned short)32) >> (unsigned short)6;
-                    U4 = as_u32(e) | (as_u32(od) << 8);
+                    Ue = ((as_us2(rBe) + as_us2(rCe)) * (unsigned short)4 + (unsigned short)32) >> (unsigned short)6;
+                    Uo = ((as_us2(rBo) + as_us2(rCo)) * (unsigned short)4 + (unsigned short)32) >> (unsigned short)6;
                 }
                 // BORDER_REPLICATE of the Gaussian: columns < 0 take column 0, columns >= sw take column sw-1
-                if (left_edge) {
-                    const unsigned e = (unsigned)__shfl((int)U4, 4) & 255u;
-                    if (lane < 4) U4 = e * 0x01010101u;
-                }
-                if (right_edge) {
-                    const unsigned e = byte_of((unsigned)__shfl((int)U4, L1 < 0 ? 0 : L1), j1);
-                    if (lane > L1) U4 = e * 0x01010101u;
-                    else if (lane == L1)
-                        for (int j = j1 + 1; j < 4; j++) U4 = (U4 & ~(255u << (8 * j))) | (e << (8 * j));
-                }
-                // horizontal [8 28 56 72 56 28 8] at the lane's 4 columns
-                unsigned H0, H1, H2, H3;
-                {
-                    const unsigned ul = up1(U4), urr = down1(U4);
-                    const unsigned K0 = 8u | (28u << 8) | (56u << 16) | (72u << 24), K1 = 56u | (28u << 8) | (8u << 16);
-                    H0 = dot4(alignb(urr, U4, 1), K1, dot4(alignb(U4, ul, 1), K0, 0));
-                    H1 = dot4(alignb(urr, U4, 2), K1, dot4(alignb(U4, ul, 2), K0, 0));
-                    H2 = dot4(alignb(urr, U4, 3), K1, dot4(alignb(U4, ul, 3), K0, 0));
-                    H3 = dot4(urr, K1, dot4(U4, K0, 0));
+                if (left_edge || right_edge) {
+                    unsigned U4 = as_u32(Ue) | (as_u32(Uo) << 8);
+                    if (left_edge) {
+                        const unsigned e = (unsigned)__shfl((int)U4, 4) & 255u;
+                        if (lane < 4) U4 = e * 0x01010101u;
+                    }
+                    if (right_edge) {
+                        const unsigned e = byte_of((unsigned)__shfl((int)U4, L1 < 0 ? 0 : L1), j1);
+                        if (lane > L1) U4 = e * 0x01010101u;
+                        else if (lane == L1)
+                            for (int j = j1 + 1; j < 4; j++) U4 = (U4 & ~(255u << (8 * j))) | (e << (8 * j));
+                    }
+                    Ue = as_us2(U4 & 0x00ff00ffu);
+                    Uo = as_us2((U4 >> 8) & 0x00ff00ffu);
                 }
                 // rows above 0 / below sh-1 replicate row 0 / sh-1; one more virtual row flushes the last mask row
                 const int vlo = (u == 0) ? -3 : u, vhi = (u == sh - 1) ? sh + 3 : u;
                 for (int vu = vlo; vu <= vhi; vu++) {
 #pragma unroll
-                    for (int k = 0; k < 6; k++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) hh[k][j] = hh[k + 1][j];
-                    hh[6][0] = H0; hh[6][1] = H1; hh[6][2] = H2; hh[6][3] = H3;
-                    ur0 = ur1; ur1 = ur2; ur2 = ur3; ur3 = U4;
-                    const int y = vu - 3;
+                    for (int k = 0; k < 6; k++) {
+                        we[k] = we[k + 1];
+                        wo[k] = wo[k + 1];
+                    }
+                    we[6] = as_u32(Ue);
+                    wo[6] = as_u32(Uo);
+                    const int y = vu - 3;   // the window now holds pyrUp rows y-3 .. y+3
                     if (y < Y0 - 1 || y > Y1 || y < 0) continue;
                     unsigned nib = 0;
                     if (y >= 1 && y <= sh - 2) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const unsigned mean = (8u * (hh[0][j] + hh[6][j]) + 28u * (hh[1][j] + hh[5][j]) + 56u * (hh[2][j] + hh[4][j]) +
-                                                   72u * hh[3][j] + 32768u) >> 16;
-                            nib |= (mean < byte_of(ur0, j) + 8u) ? (1u << j) : 0u;   // src - mean > -8 (ur0 = pyrUp row y)
-                        }
+                        // 7x7 Gaussian, vertical pass first: [8 28 56 72 56 28 8] on packed 16-bit pairs (<= 256*255 fits)
+                        const us2 Ve = (as_us2(we[0]) + as_us2(we[6])) * (unsigned short)8 + (as_us2(we[1]) + as_us2(we[5])) * (unsigned short)28 +
+                                       (as_us2(we[2]) + as_us2(we[4])) * (unsigned short)56 + as_us2(we[3]) * (unsigned short)72;
+                        const us2 Vo = (as_us2(wo[0]) + as_us2(wo[6])) * (unsigned short)8 + (as_us2(wo[1]) + as_us2(wo[5])) * (unsigned short)28 +
+                                       (as_us2(wo[2]) + as_us2(wo[4])) * (unsigned short)56 + as_us2(wo[3]) * (unsigned short)72;
+                        // horizontal pass: 16-bit column sums of this lane (V0..V3 = Ve.x Vo.x Ve.y Vo.y), the lane to the
+                        // left (l) and to the right (r), two taps per v_dot2_u32_u16.  The accumulator starts at the
+                        // rounding constant minus 8<<16:  src - mean > -8  <=>  sum + 32768 - (8<<16) < src<<16
+                        const us2 Vel = as_us2(up1(as_u32(Ve))), Vol = as_us2(up1(as_u32(Vo)));
+                        const us2 Ver = as_us2(down1(as_u32(Ve))), Vor = as_us2(down1(as_u32(Vo)));
+                        const unsigned C0 = 32768u - (8u << 16);
+                        const unsigned S0 = dot2(Vol, K2(8, 56), dot2(Vel, K2(0, 28), dot2(Ve, K2(72, 28), dot2(Vo, K2(56, 8), C0))));
+                        const unsigned S1 = dot2(Vel, K2(0, 8), dot2(Vol, K2(0, 28), dot2(Ve, K2(56, 56), dot2(Vo, K2(72, 28), dot2(Ver, K2(8, 0), C0)))));
+                        const unsigned S2 = dot2(Vol, K2(0, 8), dot2(Ve, K2(28, 72), dot2(Vo, K2(56, 56), dot2(Ver, K2(28, 0), dot2(Vor, K2(8, 0), C0)))));
+                        const unsigned S3 = dot2(Ve, K2(8, 56), dot2(Vo, K2(28, 72), dot2(Ver, K2(56, 8), dot2(Vor, K2(28, 0), C0))));
+                        const unsigned ce = we[3], co = wo[3];   // pyrUp row y itself: the threshold's source
+                        nib = (int)S3 < (int)(co & 0xffff0000u) ? 1u : 0u;
+                        nib = nib + nib + ((int)S2 < (int)(ce & 0xffff0000u) ? 1u : 0u);
+                        nib = nib + nib + ((int)S1 < (int)(co << 16) ? 1u : 0u);
+                        nib = nib + nib + ((int)S0 < (int)(ce << 16) ? 1u : 0u);
                         nib &= colmask;
                     }
-                    binw = (binw >> 4) | (nib << 8);
+                    binw = (binw >> 8) | (nib << 17);   // rows y-2, y-1, y at bytes 0, 1, 2; a row's 4 bits at bits 1..4 of its byte
                     const int yr = y - 1;
                     if (yr < Y0 || yr >= Y1) continue;
-                    // 3x3 windows of row yr from threshold rows yr-1, yr, yr+1 and the neighbour lanes' edge bits
-                    const unsigned bl = up1(binw), br = down1(binw);
-                    const unsigned A = ((bl >> 3) & 1u) | ((binw & 15u) << 1) | ((br & 1u) << 5);
-                    const unsigned M = ((bl >> 7) & 1u) | (((binw >> 4) & 15u) << 1) | (((br >> 4) & 1u) << 5);
-                    const unsigned Bw = ((bl >> 11) & 1u) | (((binw >> 8) & 15u) << 1) | (((br >> 8) & 1u) << 5);
-                    const unsigned e0 = lut[(A & 7u) | ((M & 7u) << 3) | ((Bw & 7u) << 6)];
-                    const unsigned e1 = lut[((A >> 1) & 7u) | (((M >> 1) & 7u) << 3) | (((Bw >> 1) & 7u) << 6)];
-                    const unsigned e2 = lut[((A >> 2) & 7u) | (((M >> 2) & 7u) << 3) | (((Bw >> 2) & 7u) << 6)];
-                    const unsigned e3 = lut[((A >> 3) & 7u) | (((M >> 3) & 7u) << 3) | (((Bw >> 3) & 7u) << 6)];
-                    if (out_lane)
-                        *reinterpret_cast<unsigned*>(o.nbr + nbr_addr(c0, yr, o.ns)) =
-                            (e0 & 255u) | ((e1 & 255u) << 8) | ((e2 & 255u) << 16) | ((e3 & 255u) << 24);
-                    // plausible border starts (sparse): types of the lane's 4 pixels, 2 bits each
-                    unsigned types = 0;
-                    if (out_lane) {
-                        types = (e0 >> 8) | ((e1 >> 8) << 2) | ((e2 >> 8) << 4) | ((e3 >> 8) << 6);
-                        if (c0 + 3 >= sw) types &= (c0 + 2 >= sw) ? ((c0 + 1 >= sw) ? 0x03u : 0x0fu) : 0x3fu;
-                    }
+                    // Row yr's 8-neighbour masks from threshold rows yr-1, yr, yr+1.  Each byte of Wn becomes a 6-bit window
+                    // (columns c0-1 .. c0+4) with the edge bits of the neighbour lanes; a multiplication by 0x204081 lays
+                    // copies shifted by 7, 14, 21 side by side so that byte p holds (window >> p): bits 0,1,2 = x-1, x, x+1 of
+                    // pixel p.  The row above goes through a bit reversal because directions run counter-clockwise.
+                    const unsigned Wn = binw | ((up1(binw) >> 4) & 0x010101u) | ((down1(binw) << 4) & 0x202020u);
+                    const unsigned Ms = __umul24((Wn >> 8) & 0x3fu, 0x204081u);
+                    const unsigned Bs = __umul24((Wn >> 11) & (0x3fu << 5), 0x204081u) & 0xe0e0e0e0u;   // SW S SE at bits 5..7
+                    const unsigned As = __umul24(__builtin_bitreverse32(Wn) >> 26, 0x204081u) & 0x07070707u;   // byte 3-p: NE, N, NW of pixel p
+                    const unsigned centre = (Ms >> 1) & 0x01010101u, west = Ms & 0x01010101u;
+                    const unsigned nbr4 = ((Ms >> 2) & 0x01010101u) | (__builtin_amdgcn_perm(As, As, 0x00010203u) << 1) | (west << 4) |
+                                          Bs;   // E | NE N NW | W | SW S SE
+                    if (out_lane) *reinterpret_cast<unsigned*>(o.nbr + nbr_addr(c0, yr, o.ns)) = nbr4;
+                    // plausible border starts (sparse).  Outer: foreground pixel with W, NW, N, NE all background (raster-first
+                    // pixel of a component); hole: background pixel with W and N foreground.
+                    const unsigned upper = nbr4 & 0x1e1e1e1eu;
+                    const unsigned any_upper = ((upper + 0x7f7f7f7fu) >> 7) & 0x01010101u;
+                    const unsigned outer = centre & ~any_upper & pxmask;
+                    const unsigned hole = west & (nbr4 >> 2) & ~centre & pxmask;
+                    const unsigned types = outer | (hole << 1);   // per pixel byte: 1 = outer start, 2 = hole start
                     if (__ballot(types != 0) == 0) continue;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const int type = (int)((types >> (2 * j)) & 3u) - 1;
+                        const int type = (int)((types >> (8 * j)) & 3u) - 1;
                         const unsigned long long mask = __ballot(type >= 0);
                         if (!mask) continue;
                         const int n = __popcll(mask);
@@ -314,10 +313,8 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
 }
 
 __global__ __launch_bounds__(256) void binarise_frames_kernel(Workspace ws, const uint8_t* bgr, int row_stride, size_t frame_stride) {
-    __shared__ unsigned short lut[512];
     __shared__ unsigned stage[4][MARCH_STAGE];
-    build_nbr_lut(lut);
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int unit = blockIdx.x * 4 + wave_uniform((int)(threadIdx.x >> 6));
     const int per_frame = ws.frame_strips * ws.frame_chunks;
     if (unit >= per_frame * ws.n_frames) return;
     const int f = unit / per_frame, rem = unit % per_frame;
@@ -334,7 +331,7 @@ __global__ __launch_bounds__(256) void binarise_frames_kernel(Workspace ws, cons
     o.n_cands = ws.counters + CNT_FRAME_CANDS;
     o.cap_cands = ws.cap_frame_cands;
     o.err = ws.counters + CNT_ERR;
-    march_unit<true>(bgr + (size_t)f * frame_stride, row_stride, ws.sw, ws.sh, strip, Y0, Y1, o, lut, stage[threadIdx.x >> 6]);
+    march_unit<true>(bgr + (size_t)f * frame_stride, row_stride, ws.sw, ws.sh, strip, Y0, Y1, o, stage[wave_uniform((int)(threadIdx.x >> 6))]);
 }
 
 // Odd width / height: the last column / row lies outside the even working size (opencvar.cpp:158) but is still
@@ -367,12 +364,11 @@ __global__ __launch_bounds__(256) void grey_writeback_kernel(Workspace ws, uint8
 }
 
 __global__ __launch_bounds__(256) void binarise_crops_kernel(Workspace ws) {
-    __shared__ unsigned short lut[512];
     __shared__ unsigned stage[4][MARCH_STAGE];
-    build_nbr_lut(lut);
     int n_units = ws.counters[CNT_CROP_TILES];
     if (n_units > ws.cap_crop_tiles) n_units = ws.cap_crop_tiles;
-    for (int u = blockIdx.x * 4 + (threadIdx.x >> 6); u < n_units; u += gridDim.x * 4) {
+    const int wave = wave_uniform((int)(threadIdx.x >> 6));
+    for (int u = blockIdx.x * 4 + wave; u < n_units; u += gridDim.x * 4) {
         const TileDesc td = ws.tiles_crop[u];
         const Roi r = ws.rois_crop[td.roi];
         const uint8_t* src = ws.gray + (size_t)r.frame * ws.W * ws.H + (size_t)r.y0 * ws.W + r.x0;
@@ -387,7 +383,7 @@ __global__ __launch_bounds__(256) void binarise_crops_kernel(Workspace ws) {
         o.n_cands = ws.counters + CNT_CROP_CANDS;
         o.cap_cands = ws.cap_crop_cands;
         o.err = ws.counters + CNT_ERR;
-        march_unit<false>(src, ws.W, r.sw, r.sh, td.x0, td.y0, Y1, o, lut, stage[threadIdx.x >> 6]);
+        march_unit<false>(src, ws.W, r.sw, r.sh, td.x0, td.y0, Y1, o, stage[wave]);
     }
 }
 

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
         if (TIER == 2) {
             // borders stored in the lanes' slabs: statistics, approximation and filter by the whole wave, one at a time
             unsigned long long todo = __ballot(route == 3);
-            if (todo) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // each lane stored its own slab; now every lane reads them
+            if (todo) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // each lane stored its own slab; now every lane reads them
             while (todo) {
                 const int L = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
             if (lt.npts > SLAB3_PTS) {   // more contour points than the slab holds: report, never truncate silently
                 if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_POOL_OVERFLOW);
             } else {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // the points were stored by other lanes of this wave
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // points stored by other lanes of this wave (same CU: L1 is coherent)
                 if (!wave_finish_border<CROP>(ws, c, pl, slab, lt.npts, wstack[wave])) {
                     // deeper recursion than the LDS stack holds: every lane runs the sequential routine on the same data
                     // (stack behind the points in the slab: identical writes), lane 0 publishes

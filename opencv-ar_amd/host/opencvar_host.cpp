@@ -136,6 +136,90 @@ bool read_png_gray(const char* path, std::vector<unsigned char>& gray, int& w, i
     return true;
 }
 
+// ---- camera file (opencvar.cpp:53-71) ---------------------------------------------------------------------------
+// The reference reads an OpenCV FileStorage document: `imageSize` (sequence of two ints), `cameraMatrix` and
+// `distCoeffs` (!!opencv-matrix maps with rows/cols/dt/data).  This reader understands the YAML 1.0 subset that
+// cv::FileStorage writes for those three nodes (what OpenCV's calibration sample produces) and, for XML files,
+// the equivalent <imageSize>, <cameraMatrix><data>, <distCoeffs><data> elements.
+bool slurp(const char* path, std::string& out) {
+    FILE* fp = std::fopen(path, "rb");
+    if (!fp) return false;
+    char buf[4096];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, fp)) > 0) out.append(buf, n);
+    std::fclose(fp);
+    return true;
+}
+
+// numbers of the bracketed / element list that follows position `at`, up to `closer`
+bool numbers_until(const std::string& s, size_t at, char closer, std::vector<double>& out) {
+    const size_t end = s.find(closer, at);
+    if (end == std::string::npos) return false;
+    size_t i = at;
+    while (i < end) {
+        if (std::isdigit((unsigned char)s[i]) || s[i] == '-' || s[i] == '+' || s[i] == '.') {
+            char* stop = nullptr;
+            const double v = std::strtod(s.c_str() + i, &stop);
+            if (stop == s.c_str() + i) { i++; continue; }
+            out.push_back(v);
+            i = (size_t)(stop - s.c_str());
+        } else {
+            i++;
+        }
+    }
+    return true;
+}
+
+// position just behind a top-level YAML key ("name:" at the start of a line) or an XML opening tag ("<name")
+size_t find_node(const std::string& s, const char* name, bool xml) {
+    const std::string key = xml ? std::string("<") + name : std::string(name) + ":";
+    size_t at = 0;
+    while ((at = s.find(key, at)) != std::string::npos) {
+        if (xml || at == 0 || s[at - 1] == '\n') return at + key.size();
+        at += key.size();
+    }
+    return std::string::npos;
+}
+
+bool read_node(const std::string& s, const char* name, bool xml, bool matrix, std::vector<double>& out) {
+    size_t at = find_node(s, name, xml);
+    if (at == std::string::npos) return false;
+    if (xml) {
+        if (matrix) {
+            at = s.find("<data>", at);
+            if (at == std::string::npos) return false;
+            at += 6;
+        } else {
+            at = s.find('>', at);
+            if (at == std::string::npos) return false;
+            at++;
+        }
+        return numbers_until(s, at, '<', out);
+    }
+    if (matrix) {
+        at = s.find("data:", at);
+        if (at == std::string::npos) return false;
+    }
+    at = s.find('[', at);
+    if (at == std::string::npos) return false;
+    return numbers_until(s, at + 1, ']', out);
+}
+
+bool read_camera_file(const char* path, CvarCamera* c) {
+    std::string s;
+    if (!slurp(path, s)) return false;
+    const bool xml = s.compare(0, 5, "<?xml") == 0;
+    std::vector<double> size, K, d;
+    if (!read_node(s, "imageSize", xml, false, size) || size.size() < 2) return false;
+    if (!read_node(s, "cameraMatrix", xml, true, K) || K.size() < 9) return false;
+    if (!read_node(s, "distCoeffs", xml, true, d) || d.empty()) return false;
+    c->width = (int)size[0];
+    c->height = (int)size[1];
+    for (int i = 0; i < 9; i++) c->cameraMatrix[i] = K[i];
+    for (int i = 0; i < 5; i++) c->distCoeffs[i] = i < (int)d.size() ? d[i] : 0.0;   // the reference copies 5 regardless
+    return c->width > 0 && c->height > 0;
+}
+
 bool image_ok(const IplImage* img) {
     return img && img->imageData && img->depth == IPL_DEPTH_8U && img->nChannels == 3 && img->width >= 16 && img->height >= 16 &&
            img->widthStep >= 3 * img->width;
@@ -160,16 +244,14 @@ void cvarCameraProjection(CvarCamera* c, double* p, int glstyle) {
 
 int cvarReadCamera(const char* filename, CvarCamera* c) {
     if (filename) {
-        // reference: OpenCV FileStorage YAML (opencvar.cpp:53-71).  Not provided: behaves like a
-        // file that cannot be opened.
-        std::fprintf(stderr, "opencvar: camera file '%s' not read (YAML reader not provided); returning 0\n", filename);
-        return 0;
+        if (!read_camera_file(filename, c)) return 0;   // opencvar.cpp:54-55: a file that cannot be opened returns 0
+    } else {
+        c->width = 640;
+        c->height = 480;
+        const double K[9] = {500, 0, c->width / 2.0, 0, 500, c->height / 2.0, 0, 0, 1};
+        std::memcpy(c->cameraMatrix, K, sizeof K);
+        std::memset(c->distCoeffs, 0, sizeof c->distCoeffs);
     }
-    c->width = 640;
-    c->height = 480;
-    const double K[9] = {500, 0, c->width / 2.0, 0, 500, c->height / 2.0, 0, 0, 1};
-    std::memcpy(c->cameraMatrix, K, sizeof K);
-    std::memset(c->distCoeffs, 0, sizeof c->distCoeffs);
     cvarCameraProjection(c, c->glProjection, 0);
     acMatrixTranspose(c->glProjection);
     return 1;

@@ -77,7 +77,69 @@ def test_template_loader_and_camera(host):
     assert host.cvarReadCamera(None, C.byref(cam)) == 1
     host.cvarCameraScale(C.byref(cam), 1920, 1080)
     assert bytes(cam) == bytes(ref)
-    assert host.cvarReadCamera(b"camera.yml", C.byref(cam)) == 0
+    assert host.cvarReadCamera(b"/nonexistent/camera.yml", C.byref(cam)) == 0   # opencvar.cpp:54-55
+
+
+CAMERA_YAML = """%YAML:1.0
+calibration_time: "Sun Oct  4 10:00:00 2026"
+imageSize: [ 1280, 720 ]
+flags: 0
+cameraMatrix: !!opencv-matrix
+   rows: 3
+   cols: 3
+   dt: d
+   data: [ 1.0245e+03, 0., 6.395e+02, 0.,
+       1.0251e+03, 3.5925e+02, 0., 0., 1. ]
+distCoeffs: !!opencv-matrix
+   rows: 5
+   cols: 1
+   dt: d
+   data: [ -1.25e-01, 2.5e-01, 0., -3.0e-04,
+       -1.0e-01 ]
+avg_reprojection_error: 3.1e-01
+"""
+
+CAMERA_XML = """<?xml version="1.0"?>
+<opencv_storage>
+<imageSize>
+  1280 720</imageSize>
+<cameraMatrix type_id="opencv-matrix">
+  <rows>3</rows>
+  <cols>3</cols>
+  <dt>d</dt>
+  <data>
+    1.0245e+03 0. 6.395e+02 0. 1.0251e+03 3.5925e+02 0. 0. 1.</data></cameraMatrix>
+<distCoeffs type_id="opencv-matrix">
+  <rows>5</rows>
+  <cols>1</cols>
+  <dt>d</dt>
+  <data>
+    -1.25e-01 2.5e-01 0. -3.0e-04 -1.0e-01</data></distCoeffs>
+</opencv_storage>
+"""
+
+
+@pytest.mark.parametrize("text,ext", [(CAMERA_YAML, "yml"), (CAMERA_XML, "xml")])
+def test_camera_file_reader(host, tmp_path, text, ext):
+    """cvarReadCamera(filename) (opencvar.cpp:53-71): imageSize, cameraMatrix, distCoeffs of an OpenCV FileStorage
+    document in the layout OpenCV's calibration sample writes, then the GL projection of cvarCameraProjection.
+    Parity unpinned: the reference ships no camera file and OpenCV is absent; the expected values are the file's."""
+    path = tmp_path / ("camera." + ext)
+    path.write_text(text)
+    cam = H.Camera()
+    assert host.cvarReadCamera(str(path).encode(), C.byref(cam)) == 1
+    assert (cam.width, cam.height) == (1280, 720)
+    assert list(cam.cameraMatrix) == [1024.5, 0.0, 639.5, 0.0, 1025.1, 359.25, 0.0, 0.0, 1.0]
+    assert list(cam.distCoeffs) == [-0.125, 0.25, 0.0, -3.0e-04, -0.1]
+    # glProjection = transpose of cvarCameraProjection(glstyle=0) (opencvar.cpp:73-76, 104-127)
+    p = np.zeros(16)
+    host.cvarCameraProjection(C.byref(cam), P(p), 0)
+    assert np.array_equal(np.array(list(cam.glProjection)).reshape(4, 4), p.reshape(4, 4).T)
+    assert p[0] == 2 * 1024.5 / 1280 and p[5] == 2 * 1025.1 / 720
+    # truncated document: missing distCoeffs -> 0, like a node that cannot be read
+    bad = tmp_path / ("broken." + ext)
+    bad.write_text(text[: text.index("distCoeffs")])
+    assert host.cvarReadCamera(str(bad).encode(), C.byref(cam)) == 0
 
 
 @pytest.mark.gpu
