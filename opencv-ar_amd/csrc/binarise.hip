@@ -277,7 +277,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                     // (columns c0-1 .. c0+4) with the edge bits of the neighbour lanes; a multiplication by 0x204081 lays
                     // copies shifted by 7, 14, 21 side by side so that byte p holds (window >> p): bits 0,1,2 = x-1, x, x+1 of
                     // pixel p.  The row above goes through a bit reversal because directions run counter-clockwise.
-                    const unsigned Wn = binw | ((up1(binw) >> 4) & 0x010101u) | ((down1(binw) << 4) & 0x202020u);
+                    const unsigned Wn = binw | ((up1(binw) >> 4) & 0x010101u) | ((down1(binw) << 4) & 0x202060u);   // row above: one more column (x+2 of pixel 3)
                     const unsigned Ms = __umul24((Wn >> 8) & 0x3fu, 0x204081u);
                     const unsigned Bs = __umul24((Wn >> 11) & (0x3fu << 5), 0x204081u) & 0xe0e0e0e0u;   // SW S SE at bits 5..7
                     const unsigned As = __umul24(__builtin_bitreverse32(Wn) >> 26, 0x204081u) & 0x07070707u;   // byte 3-p: NE, N, NW of pixel p
@@ -285,12 +285,16 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                     const unsigned nbr4 = ((Ms >> 2) & 0x01010101u) | (__builtin_amdgcn_perm(As, As, 0x00010203u) << 1) | (west << 4) |
                                           Bs;   // E | NE N NW | W | SW S SE
                     if (out_lane) *reinterpret_cast<unsigned*>(o.nbr + nbr_addr(c0, yr, o.ns)) = nbr4;
-                    // plausible border starts (sparse).  Outer: foreground pixel with W, NW, N, NE all background (raster-first
-                    // pixel of a component); hole: background pixel with W and N foreground.
+                    // Plausible border starts (sparse): necessary local conditions for being the raster-first pixel of a region.
+                    // Outer: foreground pixel whose W, NW, N, NE are background -- and not (E foreground and the pixel above E's
+                    // east neighbour foreground: that one belongs to the same 8-connected component and comes earlier).
+                    // Hole: background pixel whose W and N are foreground -- and E or NE foreground (if both are background they
+                    // belong to the same 4-connected background region and NE comes earlier).
                     const unsigned upper = nbr4 & 0x1e1e1e1eu;
                     const unsigned any_upper = ((upper + 0x7f7f7f7fu) >> 7) & 0x01010101u;
-                    const unsigned outer = centre & ~any_upper & pxmask;
-                    const unsigned hole = west & (nbr4 >> 2) & ~centre & pxmask;
+                    const unsigned nee = (__umul24(Wn & 0x7fu, 0x204081u) >> 3) & nbr4;   // bit 0 of byte p: E(p) & row above at x+2
+                    const unsigned outer = centre & ~any_upper & ~nee & pxmask;
+                    const unsigned hole = west & (nbr4 >> 2) & (nbr4 | (nbr4 >> 1)) & ~centre & pxmask;
                     const unsigned types = outer | (hole << 1);   // per pixel byte: 1 = outer start, 2 = hole start
                     if (__ballot(types != 0) == 0) continue;
 #pragma unroll

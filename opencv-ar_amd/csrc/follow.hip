@@ -345,18 +345,59 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
     int* ticket = ws.counters + (TIER == 1 ? (CROP ? CNT_TICKET_C : CNT_TICKET_F) : (CROP ? CNT_TICKET_MC : CNT_TICKET_MF));
     int* n_long = ws.counters + (TIER == 1 ? (CROP ? CNT_MID_C : CNT_MID_F) : (CROP ? CNT_LONG_C : CNT_LONG_F));
     const int lane = threadIdx.x & 63;
+    const int wave = uni((int)(threadIdx.x >> 6));
+    // Tier 1 sees every plausible start, and most of them are dead after a handful of steps (a staircase pixel of a
+    // slanted edge, image noise) while a few run the whole budget: a wave of 64 fresh starts would spend the full budget
+    // with almost all lanes idle.  So fresh starts first get PRE_STEPS steps each, the survivors are queued per wave in
+    // LDS, and the full-budget follow only ever runs on (nearly) full waves of survivors.
+    __shared__ StartCand wqueue[TIER == 1 ? 4 : 1][TIER == 1 ? 128 : 1];
+    int queued = 0;      // wave-uniform
+    bool more = true;    // tickets left
     for (;;) {
-        int base = 0;
-        if (ticket_lane() == 0) base = atomicAdd(ticket, 64);
-        base = uni(base);
-        if (base >= n) break;
-        const int idx = base + lane;
         StartCand c;
         c.roi = 0; c.pos = 0; c.is_hole = 0;
         int route = 0, slab_npts = 0;
-        if (idx < n) {
-            c = cands[idx];
-            route = follow_short<CROP, TIER>(ws, c, &slab_npts);
+        if (TIER == 1) {
+            while (more && queued < 64) {
+                int base = 0;
+                if (ticket_lane() == 0) base = atomicAdd(ticket, 64);
+                base = uni(base);
+                if (base >= n) {
+                    more = false;
+                    break;
+                }
+                const int idx = base + lane;
+                bool alive = false;
+                StartCand cc;
+                cc.roi = 0; cc.pos = 0; cc.is_hole = 0;
+                if (idx < n) {
+                    cc = cands[idx];
+                    const PlaneRef pl = plane_of<CROP>(ws, cc.roi);
+                    if (cc.pos > 0 && cc.pos < pl.plane)
+                        alive = trace_border<false, false>(pl.nbr, pl.ns, pl.plane, cc.pos, cc.is_hole, nullptr, 0, PRE_STEPS).status == TRACE_OVERRUN;
+                }
+                const unsigned long long mask = __ballot(alive);
+                if (alive) wqueue[wave][queued + __popcll(mask & ((1ull << lane) - 1ull))] = cc;
+                queued += __popcll(mask);
+            }
+            if (queued == 0) break;
+            const int take = queued < 64 ? queued : 64;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (lane < take) {
+                c = wqueue[wave][queued - take + lane];
+                route = follow_short<CROP, TIER>(ws, c, &slab_npts);
+            }
+            queued -= take;
+        } else {
+            int base = 0;
+            if (ticket_lane() == 0) base = atomicAdd(ticket, 64);
+            base = uni(base);
+            if (base >= n) break;
+            const int idx = base + lane;
+            if (idx < n) {
+                c = cands[idx];
+                route = follow_short<CROP, TIER>(ws, c, &slab_npts);
+            }
         }
         if (TIER == 2) {
             // borders stored in the lanes' slabs: statistics, approximation and filter by the whole wave, one at a time
@@ -372,7 +413,7 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
                 const int nl = __builtin_amdgcn_readlane(slab_npts, L);
                 const int* slab = ws.slab + ((size_t)blockIdx.x * blockDim.x + uni((int)(threadIdx.x & ~63u)) + L) * (4 * SLAB_PTS + 4);
                 const PlaneRef pl = plane_of<CROP>(ws, cl.roi);
-                if (!wave_finish_border<CROP>(ws, cl, pl, slab, nl, wstack[uni((int)(threadIdx.x >> 6))])) {
+                if (!wave_finish_border<CROP>(ws, cl, pl, slab, nl, wstack[wave])) {
                     // deeper recursion than the LDS stack holds: every lane runs the sequential routine on the same data
                     // (stack in the owner's slab: identical writes), lane 0 publishes
                     const TraceStats sp = stats_of_points(slab, nl);
@@ -392,7 +433,7 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
             int qbase = 0;
             const int leader = __ffsll((long long)mask) - 1;
             if (lane == leader) qbase = atomicAdd(count, __popcll(mask));
-            qbase = __shfl(qbase, leader);
+            qbase = __builtin_amdgcn_readlane(qbase, leader);
             if (queue) {
                 const int slot = qbase + __popcll(mask & ((1ull << lane) - 1ull));
                 if (slot < ws.cap_long) list[slot] = c;

@@ -15,6 +15,7 @@ constexpr int MARCH_STRIP = 224;           // output columns of one wave's strip
 constexpr int MARCH_CROP_ROWS = 256;       // rows per work unit in the crop pass (even)
 constexpr int MARCH_STAGE = 512;           // border starts a wave stages in LDS between two appends to the global list
 constexpr int BACK_STEPS = 32;
+constexpr int PRE_STEPS = 8;               // steps every plausible start gets before it may queue for tier 1's full budget
 constexpr int SHORT_STEPS = 96;            // step budget of follower tier 1 (every plausible start, one lane each)
 constexpr int MID_STEPS = 1536;            // step budget of tier 2 (borders that outlived tier 1, one lane each); the rest: tier 3, one wave each
 constexpr int SLAB_PTS = 1024;             // points a tier-2 lane can keep in its private slab (no second follow needed below that)

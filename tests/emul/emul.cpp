@@ -48,8 +48,8 @@ extern "C" int emul_find_contours(const uint8_t* bin, int w, int h, int* pts, in
     for (int y = 1; y < h - 1; y++)
         for (int x = 1; x < w - 1; x++) {
             int c = b(x, y);
-            bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1);
-            bool hole = !c && b(x - 1, y) && b(x, y - 1);
+            bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1) && !(b(x + 1, y) && b(x + 2, y - 1));
+            bool hole = !c && b(x - 1, y) && b(x, y - 1) && (b(x + 1, y) || b(x + 1, y - 1));
             if (!outer && !hole) continue;
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), w, w * h, y * w + x, 0, g_back)) { g_back_drops++; continue; }
             TraceStats st;
@@ -123,8 +123,8 @@ extern "C" int emul_find_squares_bin(const uint8_t* bin, int sw, int sh, int img
     for (int y = 1; y < sh - 1; y++)
         for (int x = 1; x < sw - 1; x++) {
             int c = b(x, y);
-            bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1);
-            bool hole = !c && b(x - 1, y) && b(x, y - 1);
+            bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1) && !(b(x + 1, y) && b(x + 2, y - 1));
+            bool hole = !c && b(x - 1, y) && b(x, y - 1) && (b(x + 1, y) || b(x + 1, y - 1));
             if (!outer && !hole) continue;
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, 0, g_back)) { g_back_drops++; continue; }
             st_[0]++;
@@ -194,8 +194,8 @@ extern "C" int emul_candidate_steps(const uint8_t* bin, int sw, int sh, int* typ
     for (int y = 1; y < sh - 1; y++)
         for (int x = 1; x < sw - 1; x++) {
             int c = b(x, y);
-            bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1);
-            bool hole = !c && b(x - 1, y) && b(x, y - 1);
+            bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1) && !(b(x + 1, y) && b(x + 2, y - 1));
+            bool hole = !c && b(x - 1, y) && b(x, y - 1) && (b(x + 1, y) || b(x + 1, y - 1));
             if (!outer && !hole) continue;
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, 0, g_back)) { g_back_drops++; continue; }
             TraceStats st = tb<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, 4 * sw * sh + 16);

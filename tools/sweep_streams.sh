@@ -1,0 +1,10 @@
+# throughput vs. (batch, streams); prints value and ms/step
+for cfg in "4096 4" "2048 2" "4096 8" "3072 3" "8192 4"; do
+  set -- $cfg
+  timeout -k 10 200 python bench.py --batch $1 --streams $2 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/ss_$1_$2.json 2>gpurun_out/ss_$1_$2.err || { echo "fail $cfg"; tail -3 gpurun_out/ss_$1_$2.err; continue; }
+  python - <<PY
+import json
+d = json.loads(open("gpurun_out/ss_$1_$2.json").read().strip().splitlines()[-1])
+print("$1 $2", d["value"], d["ms_per_step"])
+PY
+done
