@@ -24,6 +24,12 @@ constexpr int SV = MARCH_STRIP;  // output columns per strip (lanes 4..59)
 // which the compiler must treat as per-lane: without this every row counter of the march lives in a VGPR, every loop
 // test is a VALU compare + EXEC mask, and every row address is 64-bit VALU arithmetic.
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a wave-uniform 64-bit offset, pinned to an SGPR pair (row offsets: the per-lane part of an address is then a 32-bit add)
+__device__ __forceinline__ long long wave_uniform64(long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -34,8 +40,8 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 __device__ __forceinline__ unsigned grey_of(unsigned b, unsigned g, unsigned r) { return (b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14; }
 
 // lane i receives lane i-1 / lane i+1 (DPP whole-wave shifts: one VALU move, no LDS traffic)
-__device__ __forceinline__ unsigned up1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ unsigned down1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned up1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned down1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(unsigned v) { return __builtin_bit_cast(us2, v); }
@@ -86,6 +92,10 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         xr2 = reflect101(c0 + 2, sw) * (BGR ? 3 : 1);
         xr3 = reflect101(c0 + 3, sw) * (BGR ? 3 : 1);
     }
+    // per-lane byte offsets (unsigned: the row bases are wave-uniform, so loads/stores can use the SGPR-base + 32-bit VGPR offset form)
+    const unsigned src_off = fast ? (unsigned)(c0 * (BGR ? 3 : 1)) : 0u;
+    const unsigned out_off = out_lane ? (unsigned)c0 : 0u;
+    const unsigned nbr_off = out_lane ? nbr_col_off(c0) : 0u;
     unsigned colmask = 0;  // which of the lane's 4 columns lie inside cvFindContours' zeroed frame
     for (int j = 0; j < 4; j++) colmask |= (c0 + j >= 1 && c0 + j <= sw - 2) ? (1u << j) : 0u;
     unsigned pxmask = 0;   // bit 8j: the lane's pixel j is an output pixel of this strip
@@ -121,20 +131,20 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     auto fetch = [&](int v) -> Raw {
         Raw r = {0u, 0u, 0u};
         if (!needed) return r;
-        const uint8_t* row = src + (long long)reflect101(v, sh) * src_stride;
+        const uint8_t* row = src + wave_uniform64((long long)reflect101(v, sh) * src_stride);
         if (fast) {
             if (BGR) {
                 if (aligned) {
-                    const unsigned* p = reinterpret_cast<const unsigned*>(row + 3 * c0);
+                    const unsigned* p = reinterpret_cast<const unsigned*>(row + src_off);
                     r.d0 = p[0]; r.d1 = p[1]; r.d2 = p[2];
                 } else {
-                    const uint8_t* p = row + 3 * c0;
+                    const uint8_t* p = row + src_off;
                     r.d0 = p[0] | (p[1] << 8) | (p[2] << 16) | ((unsigned)p[3] << 24);
                     r.d1 = p[4] | (p[5] << 8) | (p[6] << 16) | ((unsigned)p[7] << 24);
                     r.d2 = p[8] | (p[9] << 8) | (p[10] << 16) | ((unsigned)p[11] << 24);
                 }
             } else {
-                const uintptr_t a = reinterpret_cast<uintptr_t>(row + c0);
+                const uintptr_t a = reinterpret_cast<uintptr_t>(row + src_off);
                 const unsigned* p = reinterpret_cast<const unsigned*>(a & ~(uintptr_t)3);
                 r.d0 = alignb(p[1], p[0], (unsigned)(a & 3));
             }
@@ -174,7 +184,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         if (v < v_last) nxt = fetch(v + 1);  // issue the next row's loads before this row's arithmetic
         const unsigned g = to_grey(cur);
         if (BGR && o.gray && out_lane && v >= Y0 && v < Y1) {  // rows [Y0,Y1) are real rows, each loaded exactly once
-            uint8_t* q = o.gray + (long long)v * o.gray_stride + c0;
+            uint8_t* q = o.gray + wave_uniform64((long long)v * o.gray_stride) + out_off;
             if (gray_dword) *reinterpret_cast<unsigned*>(q) = g;
             else
                 for (int j = 0; j < 4; j++)
@@ -284,7 +294,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                     const unsigned centre = (Ms >> 1) & 0x01010101u, west = Ms & 0x01010101u;
                     const unsigned nbr4 = ((Ms >> 2) & 0x01010101u) | (__builtin_amdgcn_perm(As, As, 0x00010203u) << 1) | (west << 4) |
                                           Bs;   // E | NE N NW | W | SW S SE
-                    if (out_lane) *reinterpret_cast<unsigned*>(o.nbr + nbr_addr(c0, yr, o.ns)) = nbr4;
+                    if (out_lane) *reinterpret_cast<unsigned*>(o.nbr + wave_uniform64(nbr_row_off(yr, o.ns)) + nbr_off) = nbr4;
                     // Plausible border starts (sparse): necessary local conditions for being the raster-first pixel of a region.
                     // Outer: foreground pixel whose W, NW, N, NE are background -- and not (E foreground and the pixel above E's
                     // east neighbour foreground: that one belongs to the same 8-connected component and comes earlier).

@@ -36,6 +36,21 @@ OCVAR_HD long long nbr_addr(int x, int y, int ns) {
     return (long long)y * ns + x;
 #endif
 }
+// the same offset split into its row part (wave-uniform in the row-marching kernels) and its column part (constant per lane)
+OCVAR_HD long long nbr_row_off(int y, int ns) {
+#if defined(OCVAR_NBR_TILED)
+    return ((long long)((y >> 3) * (ns >> 4)) << 7) + ((y & 7) << 4);
+#else
+    return (long long)y * ns;
+#endif
+}
+OCVAR_HD unsigned nbr_col_off(int x) {
+#if defined(OCVAR_NBR_TILED)
+    return ((unsigned)(x >> 4) << 7) + (unsigned)(x & 15);
+#else
+    return (unsigned)x;
+#endif
+}
 OCVAR_HD long long nbr_plane_bytes(int ns, int sh) { return (long long)ns * ((sh + 7) & ~7); }
 
 // One region of interest handed to the square finder: a whole frame (frame pass) or the clipped
