@@ -109,7 +109,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         int base = 0;
         if (lane == 0) base = atomicAdd(o.n_cands, staged);
-        base = __shfl(base, 0);
+        base = wave_uniform(base);
         for (int i = lane; i < staged; i += 64) {
             const unsigned e = stage[i];
             if (base + i < o.cap_cands) {
@@ -232,11 +232,11 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                 if (left_edge || right_edge) {
                     unsigned U4 = as_u32(Ue) | (as_u32(Uo) << 8);
                     if (left_edge) {
-                        const unsigned e = (unsigned)__shfl((int)U4, 4) & 255u;
+                        const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)U4, 4) & 255u;
                         if (lane < 4) U4 = e * 0x01010101u;
                     }
                     if (right_edge) {
-                        const unsigned e = byte_of((unsigned)__shfl((int)U4, L1 < 0 ? 0 : L1), j1);
+                        const unsigned e = byte_of((unsigned)__builtin_amdgcn_readlane((int)U4, L1 < 0 ? 0 : L1), j1);
                         if (lane > L1) U4 = e * 0x01010101u;
                         else if (lane == L1)
                             for (int j = j1 + 1; j < 4; j++) U4 = (U4 & ~(255u << (8 * j))) | (e << (8 * j));

@@ -102,6 +102,37 @@ def test_config3_full_hd_three_templates(oa):
         assert n_c >= 36 and 1 <= len(ref_m) <= 3
 
 
+def test_padded_rows_gapped_frames_and_unaligned_base(oa):
+    """IplImage.widthStep may exceed 3*width and imageData need not be 4-byte aligned (opencvar.cpp:619 takes any
+    8UC3 image): rows padded to 3*W+5 bytes, frames 77 bytes apart, base pointer at an odd address -- the kernel's
+    byte-load path -- and grey written back in place into that layout."""
+    import torch
+    cfg = H.synth_config(2, width=644, height=482)
+    n = 3
+    det, tpls, cam = make_detector(oa, cfg, ["2x2-01"], n)
+    frames = [H.synth_frame(cfg, f, ["2x2-01"])[0] for f in range(n)]
+    w, h = cfg.width, cfg.height
+    row_stride = 3 * w + 5
+    frame_stride = row_stride * h + 77
+    buf = np.full(1 + n * frame_stride, 0xA5, np.uint8)
+    for f in range(n):
+        rows = buf[1 + f * frame_stride: 1 + f * frame_stride + row_stride * h].reshape(h, row_stride)
+        rows[:, :3 * w] = frames[f].reshape(h, 3 * w)
+    d = torch.from_numpy(buf).cuda()
+    assert (d.data_ptr() + 1) % 2 == 1
+    markers, counts = det.detect_device(d.data_ptr() + 1, w, h, n, row_stride=row_stride, frame_stride=frame_stride,
+                                        grey_in_place=True)
+    out = d.cpu().numpy()
+    for f in range(n):
+        ref_m, n_c = check_frame(det, f, frames[f], tpls, cam, markers, counts)
+        assert n_c >= 3
+        _, _, grey = H.oracle_registration(frames[f], tpls, cam)
+        rows = out[1 + f * frame_stride: 1 + f * frame_stride + row_stride * h].reshape(h, row_stride)
+        assert np.array_equal(rows[:, :3 * w].reshape(h, w, 3), grey)
+        assert (rows[:, 3 * w:] == 0xA5).all()          # padding untouched
+    assert out[0] == 0xA5 and (out[1 + (n - 1) * frame_stride + row_stride * h:] == 0xA5).all()
+
+
 def test_textured_background_and_odd_size(oa):
     cfg = H.synth_config(3, textured=1, width=1001, height=701, grid_x=2, grid_y=2)
     det, tpls, cam = make_detector(oa, cfg, None, 2)
