@@ -27,6 +27,9 @@ struct OcvarHip {
     std::vector<void*> allocs;
     uint8_t* d_frames = nullptr;  // staging for the host-buffer entry points
     size_t d_frames_bytes = 0;
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;   // host transport of ocvar_hip_detect_host (created on first use)
+    std::vector<hipEvent_t> h2d_done;
+    hipEvent_t computed = nullptr;
     MarkerRec* h_markers = nullptr;  // pinned
     int* h_counts = nullptr;         // pinned
     int* h_counters = nullptr;       // pinned
@@ -138,6 +141,10 @@ extern "C" void ocvar_hip_destroy(OcvarHip* c) {
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->h2d_done) (void)hipEventDestroy(e);
+    if (c->computed) (void)hipEventDestroy(c->computed);
+    if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
+    if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -327,8 +334,7 @@ extern "C" int ocvar_hip_detect_device(OcvarHip* c, uint8_t* d_bgr, int width, i
     return ocvar_hip_collect(c, markers, counts, max_per_frame);
 }
 
-static int stage_frames(OcvarHip* c, const uint8_t* h, int height, int row_stride, size_t frame_stride, int n_frames) {
-    const size_t bytes = (size_t)(n_frames - 1) * frame_stride + (size_t)height * row_stride;
+static int reserve_staging(OcvarHip* c, size_t bytes) {
     if (bytes > c->d_frames_bytes) {
         if (c->d_frames) (void)hipFree(c->d_frames);
         c->d_frames = nullptr;
@@ -336,25 +342,103 @@ static int stage_frames(OcvarHip* c, const uint8_t* h, int height, int row_strid
         HIP_TRY(c, hipMalloc((void**)&c->d_frames, bytes));
         c->d_frames_bytes = bytes;
     }
+    return OCVAR_OK;
+}
+
+static int stage_frames(OcvarHip* c, const uint8_t* h, int height, int row_stride, size_t frame_stride, int n_frames) {
+    const size_t bytes = (size_t)(n_frames - 1) * frame_stride + (size_t)height * row_stride;
+    int rc = reserve_staging(c, bytes);
+    if (rc) return rc;
     HIP_TRY(c, hipMemcpy(c->d_frames, h, bytes, hipMemcpyHostToDevice));
     return OCVAR_OK;
 }
+
+// Frames in host memory.  The caller's buffer is page-locked in place for the duration of the call
+// (hipHostRegister; a buffer the caller registered already is used as it is), all sub-batches' host-to-device copies are
+// queued up front on a copy stream, and each sub-batch is detected as soon as its copy has landed -- so the PCIe
+// transfer of sub-batch k+1.. overlaps the kernels of sub-batch k.  The in-place grey of the reference
+// (opencvar.cpp:624-627) travels back on a third stream.  If the buffer cannot be page-locked the call falls back to
+// one synchronous copy (same results).
+constexpr int HOST_SUB_BATCH = 64;
 
 extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,
                                      int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts,
                                      OcvarMarker* markers, int* counts, int max_per_frame) {
     if (!c || !h_bgr || n_frames < 1 || height < 1 || row_stride < 1) return OCVAR_E_ARG;
     if (n_frames > 1 && frame_stride < (size_t)height * row_stride) return OCVAR_E_ARG;
+    if (!counts || max_per_frame < 0 || (max_per_frame > 0 && !markers)) return OCVAR_E_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = stage_frames(c, h_bgr, height, row_stride, frame_stride, n_frames);
+    const size_t frame_bytes = (size_t)height * row_stride;
+    const size_t bytes = (size_t)(n_frames - 1) * frame_stride + frame_bytes;
+    int rc = reserve_staging(c, bytes);
     if (rc) return rc;
-    rc = ocvar_hip_detect_device(c, c->d_frames, width, height, row_stride, frame_stride, n_frames, grey_in_place, prev,
-                                 prev_counts, markers, counts, max_per_frame);
-    if (rc) return rc;
-    if (grey_in_place) {
-        const size_t bytes = (size_t)(n_frames - 1) * frame_stride + (size_t)height * row_stride;
-        HIP_TRY(c, hipMemcpy(h_bgr, c->d_frames, bytes, hipMemcpyDeviceToHost));
+
+    bool registered_here = false, pinned = false;
+    if (n_frames > 1) {
+        const hipError_t e = hipHostRegister(h_bgr, bytes, hipHostRegisterDefault);
+        if (e == hipSuccess) registered_here = pinned = true;
+        else if (e == hipErrorHostMemoryAlreadyRegistered) pinned = true;
+        (void)hipGetLastError();
     }
+    if (!pinned) {
+        HIP_TRY(c, hipMemcpy(c->d_frames, h_bgr, bytes, hipMemcpyHostToDevice));
+        rc = ocvar_hip_detect_device(c, c->d_frames, width, height, row_stride, frame_stride, n_frames, grey_in_place, prev,
+                                     prev_counts, markers, counts, max_per_frame);
+        if (rc) return rc;
+        if (grey_in_place) HIP_TRY(c, hipMemcpy(h_bgr, c->d_frames, bytes, hipMemcpyDeviceToHost));
+        return OCVAR_OK;
+    }
+
+    auto fail = [&](int code) {
+        (void)hipDeviceSynchronize();
+        if (registered_here) (void)hipHostUnregister(h_bgr);
+        return code;
+    };
+#define HIP_TRY_HOST(expr)                                            \
+    do {                                                              \
+        hipError_t e_ = (expr);                                       \
+        if (e_ != hipSuccess) {                                       \
+            c->err = std::string(#expr) + ": " + hipGetErrorString(e_); \
+            return fail(OCVAR_E_HIP);                                 \
+        }                                                             \
+    } while (0)
+    if (!c->h2d_stream) HIP_TRY_HOST(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+    if (!c->d2h_stream) HIP_TRY_HOST(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+    if (!c->computed) HIP_TRY_HOST(hipEventCreateWithFlags(&c->computed, hipEventDisableTiming));
+    const int sub = c->ws.max_batch < HOST_SUB_BATCH ? c->ws.max_batch : HOST_SUB_BATCH;
+    const int n_sub = (n_frames + sub - 1) / sub;
+    while ((int)c->h2d_done.size() < n_sub) {
+        hipEvent_t ev;
+        HIP_TRY_HOST(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c->h2d_done.push_back(ev);
+    }
+    auto span = [&](int k, size_t* off, int* cnt) {
+        *cnt = (k + 1) * sub <= n_frames ? sub : n_frames - k * sub;
+        *off = (size_t)k * sub * frame_stride;
+        return (size_t)(*cnt - 1) * frame_stride + frame_bytes;
+    };
+    for (int k = 0; k < n_sub; k++) {
+        size_t off;
+        int cnt;
+        const size_t len = span(k, &off, &cnt);
+        HIP_TRY_HOST(hipMemcpyAsync(c->d_frames + off, h_bgr + off, len, hipMemcpyHostToDevice, c->h2d_stream));
+        HIP_TRY_HOST(hipEventRecord(c->h2d_done[k], c->h2d_stream));
+    }
+    for (int k = 0; k < n_sub; k++) {
+        size_t off;
+        int cnt;
+        const size_t len = span(k, &off, &cnt);
+        HIP_TRY_HOST(hipStreamWaitEvent(c->stream, c->h2d_done[k], 0));
+        rc = ocvar_hip_detect_device(c, c->d_frames + off, width, height, row_stride, frame_stride, cnt, grey_in_place,
+                                     prev ? prev + (size_t)k * sub * MAXM : nullptr, prev_counts ? prev_counts + k * sub : nullptr,
+                                     markers ? markers + (size_t)k * sub * max_per_frame : nullptr, counts + k * sub, max_per_frame);
+        if (rc) return fail(rc);
+        if (grey_in_place)   // detect_device returned after the sub-batch's kernels finished
+            HIP_TRY_HOST(hipMemcpyAsync(h_bgr + off, c->d_frames + off, len, hipMemcpyDeviceToHost, c->d2h_stream));
+    }
+    if (grey_in_place) HIP_TRY_HOST(hipStreamSynchronize(c->d2h_stream));
+#undef HIP_TRY_HOST
+    if (registered_here) HIP_TRY(c, hipHostUnregister(h_bgr));
     return OCVAR_OK;
 }
 

@@ -133,6 +133,28 @@ def test_padded_rows_gapped_frames_and_unaligned_base(oa):
     assert out[0] == 0xA5 and (out[1 + (n - 1) * frame_stride + row_stride * h:] == 0xA5).all()
 
 
+def test_host_entry_pipelines_sub_batches(oa):
+    """ocvar_hip_detect_host with more frames than the context's batch: the caller's buffer is page-locked in place,
+    copies of later sub-batches overlap detection of earlier ones, grey comes back in place."""
+    cfg = H.synth_config(2)
+    det, tpls, cam = make_detector(oa, cfg, ["2x2-01"], 2)   # sub-batches of 2
+    n = 5
+    frames = np.stack([H.synth_frame(cfg, f, ["2x2-01"])[0] for f in range(n)])
+    work = frames.copy()
+    markers, counts = det.detect_host(work, grey_in_place=True)
+    assert counts.shape == (n,)
+    for f in range(n):
+        ref_m, _, grey = H.oracle_registration(frames[f], tpls, cam)
+        assert np.array_equal(work[f], grey)
+        assert counts[f] == len(ref_m)
+        for k, r in enumerate(ref_m):
+            m = markers[f, k]
+            assert m["templateId"] == r.templateId and m["markerId"] == r.markerId and m["score"] == r.score
+            assert np.abs(m["square"] - np.array(r.square)).max() <= CORNER_TOL
+            g = np.array(r.glMatrix)
+            assert np.abs(m["glMatrix"] - g).max() <= POSE_RTOL * max(1.0, np.abs(g).max())
+
+
 def test_textured_background_and_odd_size(oa):
     cfg = H.synth_config(3, textured=1, width=1001, height=701, grid_x=2, grid_y=2)
     det, tpls, cam = make_detector(oa, cfg, None, 2)

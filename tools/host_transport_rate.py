@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Frames in host memory -> markers in host memory through ocvar_hip_detect_host (PCIe-inclusive rate)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import helpers as H
+import opencv_ar_amd as oa
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+cfg = H.synth_config(3)
+base = np.stack([H.synth_frame(cfg, i)[0] for i in range(16)])
+frames = np.concatenate([base] * (B // 16))
+tpls, cam = H.oracle_templates(), H.oracle_camera(cfg.width, cfg.height)
+det = oa.Detector(cfg.width, cfg.height, max_batch=64)
+det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls]); det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+for grey in (False, True):
+    det.detect_host(frames.copy(), grey_in_place=grey)
+    work = frames.copy()
+    t0 = time.perf_counter()
+    m, c = det.detect_host(work, grey_in_place=grey)
+    dt = time.perf_counter() - t0
+    print(f"detect_host {B} frames 1920x1080, grey_in_place={grey}: {B / dt:.0f} frames/s, {B * frames[0].nbytes / dt / 1e9:.1f} GB/s host->device"
+          f"{' + back' if grey else ''}, markers/frame {c.mean():.2f}")
