@@ -56,3 +56,13 @@ def test_frame_sharding_covers_every_frame_once():
     for world in (1, 2, 4, 8):
         seen = sorted(S.frame_of(r, world, i) for r in range(world) for i in range(6))
         assert seen == list(range(6 * world))
+
+
+def test_stream_sharding_covers_every_stream_once():
+    sys.path.insert(0, ROOT)
+    from opencv_ar_amd.tracking import streams_of
+    for world in (1, 2, 3, 8):
+        for n in (1, 5, 8, 13):
+            owned = [streams_of(r, world, n) for r in range(world)]
+            assert sorted(s for o in owned for s in o) == list(range(n))
+            assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1

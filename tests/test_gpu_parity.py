@@ -215,6 +215,23 @@ def test_stateful_tracking_second_call(oa):
         check_frame(det, f, frames[f], tpls, cam, m2, c2, prev=ref1)
 
 
+def test_stream_tracker_three_steps_two_streams(oa):
+    """Two video streams, three time steps: lane s of every batch is stream s and gets stream s's markers of the
+    previous step (opencvar.cpp:635-668) -- against the oracle run sequentially per stream."""
+    from opencv_ar_amd.tracking import StreamTracker
+    cfg = H.synth_config(2)
+    det, tpls, cam = make_detector(oa, cfg, ["2x2-01"], 2)
+    tracker = StreamTracker(det, 2)
+    seq = {0: [3, 4, 4], 1: [7, 7, 8]}   # synthetic frame index per step (a repeated frame tracks onto itself)
+    ref_prev = {0: None, 1: None}
+    for t in range(3):
+        frames = np.stack([H.synth_frame(cfg, seq[s][t], ["2x2-01"])[0] for s in (0, 1)])
+        markers, counts = tracker.step(frames.copy())
+        for s in (0, 1):
+            check_frame(det, s, frames[s], tpls, cam, markers, counts, prev=ref_prev[s])
+            ref_prev[s], _, _ = H.oracle_registration(frames[s], tpls, cam, prev=ref_prev[s])
+
+
 def test_round_trip_properties_full_size(oa):
     """Size-independent properties at the headline size: determinism across batch positions, and every decoded
     4x4 marker's quad lies on a planted marker (corner within 12 px of the truth: the decoded quad is the inner border)."""
