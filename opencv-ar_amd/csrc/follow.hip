@@ -303,7 +303,18 @@ __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand
     const int BUDGET = TIER == 1 ? SHORT_STEPS : ws.mid_steps;
     const PlaneRef pl = plane_of<CROP>(ws, c.roi);
     if (c.pos <= 0 || c.pos >= pl.plane) return false;
-    if (TIER == 1 && !c.is_hole && earlier_start_behind(pl.nbr, pl.ns, pl.plane, c.pos, 0, BACK_STEPS)) return false;
+    if (TIER == 1) {
+        // tier 1 only decides where a start goes: a look behind (outer starts), then SHORT_STEPS store-free steps.
+        // Dead (not the border's first position, isolated pixel, fewer than 4 corner points): dropped.  Closed within the
+        // budget or still running: tier 2, which follows again with point storage -- or straight to the wave tier when
+        // the border barely turned in SHORT_STEPS steps (an image-sized straight border would only burn tier 2's whole
+        // budget before getting there anyway).
+        if (!c.is_hole && earlier_start_behind(pl.nbr, pl.ns, pl.plane, c.pos, 0, BACK_STEPS)) return 0;
+        const LeanTrace lt = trace_lean(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
+        if (lt.status == TRACE_OVERRUN) return lt.npts <= 2 ? 2 : 1;
+        if (lt.status != TRACE_OK || lt.npts < 4) return 0;
+        return 1;
+    }
     if (TIER == 2) {
         // tier 2 stores the points while it follows (lean loop, private slab): a border that fits needs no second
         // follow, and its statistics come from the stored points
@@ -316,11 +327,9 @@ __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand
             return 3;
         }
     }
-    // tier 1, and tier-2 borders with more points than a slab holds: statistics first, then a storing follow
+    // tier-2 borders with more points than a slab holds: statistics first, then a storing follow into the pool
     const TraceStats st = trace_border<false, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
-    // budget exhausted: next tier -- or, from tier 1, straight to the wave tier when the border barely turned in 96 steps
-    // (image-sized straight borders would only burn tier 2's whole budget before getting there anyway)
-    if (st.status == TRACE_OVERRUN) return (TIER == 1 && st.npts <= 2) ? 2 : 1;
+    if (st.status == TRACE_OVERRUN) return 1;
     if (!worth_approximating(st)) return false;
     const int need = 2 * st.npts + 2 * (st.npts + 2);
     const long long off = atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
                     cc = cands[idx];
                     const PlaneRef pl = plane_of<CROP>(ws, cc.roi);
                     if (cc.pos > 0 && cc.pos < pl.plane)
-                        alive = trace_border<false, false>(pl.nbr, pl.ns, pl.plane, cc.pos, cc.is_hole, nullptr, 0, PRE_STEPS).status == TRACE_OVERRUN;
+                        alive = trace_lean(pl.nbr, pl.ns, pl.plane, cc.pos, cc.is_hole, nullptr, 0, PRE_STEPS).status == TRACE_OVERRUN;
                 }
                 const unsigned long long mask = __ballot(alive);
                 if (alive) wqueue[wave][queued + __popcll(mask & ((1ull << lane) - 1ull))] = cc;
