@@ -94,39 +94,67 @@ def main():
     d_res = torch.empty(S.block_bytes(B), dtype=torch.uint8, device="cuda")
     nbytes_m = B * S.MAX_MARKERS * S.MARKER_BYTES
 
-    stage_sum = np.zeros(12, np.float64)
+    # K steps as a software pipeline.  Every context runs its sub-batches back to back on its own stream; the contexts are
+    # staggered by 1/NS of a sub-batch (context i's first launch covers (i+1)/NS of its sub-batch, its last launch the
+    # rest), because contexts that start together stay in lock-step -- all four in the VALU-bound binarise kernels, then
+    # all four in the latency-bound followers -- and nothing overlaps.  Per context: first + (K-1) full + rest = K
+    # sub-batches; the host only ever waits for the context whose launch is oldest.
+    stage_full = np.zeros(12, np.float64)   # per-kernel event times of full-size launches inside the timed region
+    n_full = [0]
+    frames_done = [0]
+    last = {}
 
-    def step(timed):
-        for i in range(NS):
-            dets[i].enqueue_device(d_frames.data_ptr() + int(offs[i]) * frame_bytes, W, Hh, sub[i], stream=streams[i].cuda_stream)
-            if world > 1:
-                dets[i].results_to_device(d_res.data_ptr() + int(offs[i]) * S.MAX_MARKERS * S.MARKER_BYTES,
-                                          d_res.data_ptr() + nbytes_m + 4 * int(offs[i]), streams[i].cuda_stream)
-        parts = [dets[i].collect(8) for i in range(NS)]
-        markers = np.concatenate([p[0] for p in parts])
-        counts = np.concatenate([p[1] for p in parts])
+    def enqueue(i, n):
+        dets[i].enqueue_device(d_frames.data_ptr() + int(offs[i]) * frame_bytes, W, Hh, n, stream=streams[i].cuda_stream)
         if world > 1:
-            blocks = S.gather_blocks(d_res, rank, world, dist)   # all sub-batches are complete (collect waited)
-            torch.cuda.current_stream().synchronize()
-            if rank == 0 and not timed:
-                S.unpack(blocks, B, oa.MARKER_DTYPE)  # warm-up only: checks the gathered blocks decode
-        if timed:
-            for i in range(NS):
-                stage_sum[:] += dets[i].stage_ms() * (sub[i] / B)   # batch-weighted mean over the contexts
-        return markers, counts
+            dets[i].results_to_device(d_res.data_ptr() + int(offs[i]) * S.MAX_MARKERS * S.MARKER_BYTES,
+                                      d_res.data_ptr() + nbytes_m + 4 * int(offs[i]), streams[i].cuda_stream)
+        last[i] = n
 
-    for _ in range(args.warmup):
-        markers, counts = step(False)
+    def collect(i, timed):
+        m, c = dets[i].collect(8)
+        frames_done[0] += last[i]
+        if timed and last[i] == sub[i]:
+            stage_full[:] += dets[i].stage_ms()
+            n_full[0] += 1
+        return m, c
+
+    def run(K, timed):
+        first = [max(1, ((i + 1) * sub[i]) // NS) for i in range(NS)]
+        parts = [None] * NS
+        for i in range(NS):
+            enqueue(i, first[i])
+        for k in range(K):
+            for i in range(NS):
+                parts[i] = collect(i, timed)
+                n = sub[i] if k < K - 1 else sub[i] - first[i]
+                if n > 0:
+                    enqueue(i, n)
+                else:
+                    last.pop(i)
+            if world > 1:   # one gather of the ranks' result blocks per step (all of the step's launches are complete)
+                blocks = S.gather_blocks(d_res, rank, world, dist)
+                torch.cuda.current_stream().synchronize()
+                if rank == 0 and not timed:
+                    S.unpack(blocks, B, oa.MARKER_DTYPE)  # warm-up only: checks the gathered blocks decode
+        for i in list(last):
+            parts[i] = collect(i, timed)
+            last.pop(i)
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+    if args.warmup > 0:
+        markers, counts = run(args.warmup, False)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    frames_done[0] = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        markers, counts = step(True)
+    markers, counts = run(args.steps, True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    assert frames_done[0] == B * args.steps, (frames_done[0], B, args.steps)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -145,9 +173,9 @@ def main():
     if rank == 0:
         K = args.steps
         fps = world * B * K / dt
-        stage_ms = stage_sum / K
+        stage_ms = stage_full / max(1, n_full[0])   # mean over the full-size launches of the timed region
         crop_pixels = sum(float(d.counters()[4]) for d in dets) / B
-        n_out = float(counts.sum()) / B
+        n_out = float(counts.sum()) / max(1, len(counts))
         # algorithmic bytes per frame = 6*W*H + sum of crop areas + 184 per output marker
         alg_frame = 6.0 * W * Hh + crop_pixels + 184.0 * n_out
         # Per-kernel mean launch duration (HIP events on the launch streams, timed region) and algorithmic bytes per
