@@ -29,11 +29,18 @@ struct Pt { int x, y; };
 // line -- because the border follower walks locally in 2-D: with raster rows every vertical step of a border is
 // a new 128-byte line (a fresh HBM/MALL miss on a dependent chain), with tiles a walk stays in a line for ~10 steps.
 // The host-side test build of the cores keeps plain raster planes.
-OCVAR_HD long long nbr_addr(int x, int y, int ns) {
+// (A plane is far smaller than 4 GB; the offset is 32-bit and, on the device, built with the 24-bit multiplier: the
+// followers compute it once per step on a dependent chain.)
+OCVAR_HD unsigned nbr_addr(int x, int y, int ns) {
 #if defined(OCVAR_NBR_TILED)
-    return ((long long)((y >> 3) * (ns >> 4) + (x >> 4)) << 7) + ((y & 7) << 4) + (x & 15);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned tile = __umul24((unsigned)(y >> 3), (unsigned)(ns >> 4)) + (unsigned)(x >> 4);
 #else
-    return (long long)y * ns + x;
+    const unsigned tile = (unsigned)(y >> 3) * (unsigned)(ns >> 4) + (unsigned)(x >> 4);
+#endif
+    return (tile << 7) | ((unsigned)(y & 7) << 4) | (unsigned)(x & 15);
+#else
+    return (unsigned)(y * ns + x);
 #endif
 }
 // the same offset split into its row part (wave-uniform in the row-marching kernels) and its column part (constant per lane)

@@ -203,6 +203,14 @@ struct LeanTrace {
     int steps;
 };
 
+// dy * ns for dy in {-1,0,1}: the 24-bit multiplier on the device (a full 32-bit multiply is quarter rate)
+OCVAR_HD int mul_small(int d, int ns) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(d, ns);
+#else
+    return d * ns;
+#endif
+}
 OCVAR_HD int step_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }   // 1,1,0,-1,-1,-1,0,1
 OCVAR_HD int step_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }   // 0,-1,-1,-1,0,1,1,1
 
@@ -241,7 +249,7 @@ OCVAR_HD LeanTrace trace_lean(const uint8_t* nbr, int ns, int plane, int cpos, i
         const int ex = x, ey = y;
         prev_s = e;
         const int dx = step_dx(e), dy = step_dy(e);
-        const int nidx = idx + dy * ns + dx;
+        const int nidx = idx + mul_small(dy, ns) + dx;
         x += dx;
         y += dy;
         if (nidx == i0 && idx == i1) {
