@@ -74,8 +74,10 @@ def main():
     # frame index space is sharded by frame: rank r owns frames r, r+world, ...
     base = np.stack([H.synth_frame(cfg, S.frame_of(rank, world, i), names)[0] for i in range(uniq)])
     frames = np.concatenate([base] * ((B + uniq - 1) // uniq))[:B]
-    tpls = H.oracle_templates(names)   # template codes / camera are setup-side data structures
-    cam = H.oracle_camera(W, Hh)
+    # setup side through the product's own host library (cvarLoadTemplateTag on the PNGs, cvarReadCamera(NULL) +
+    # cvarCameraScale); the oracle is only touched by the cpu_baseline leg below
+    tpl_list = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, n + ".png") for n in (names or H.TEMPLATE_ORDER)])
+    camera = oa.default_camera(W, Hh)
     # The batch is split over `streams` independent contexts, each with its own HIP stream and workspace, so that the
     # latency-bound kernels of one sub-batch (border following) overlap the streaming kernels of another.
     NS = max(1, min(args.streams, B))
@@ -84,8 +86,8 @@ def main():
     dets, streams = [], []
     for i in range(NS):
         det = oa.Detector(W, Hh, max_batch=sub[i], device=local_rank)
-        det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls])
-        det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+        det.set_templates(tpl_list)
+        det.set_camera(camera)
         dets.append(det)
         streams.append(torch.cuda.Stream())
     det = dets[0]
@@ -226,7 +228,8 @@ def main():
             "markers_per_frame": round(n_out, 3),
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, tpls, cam)
+            tpls = (H.Template * len(tpl_list))(*[H.Template.from_buffer_copy(bytes(t)) for t in tpl_list])
+            out["cpu_baseline"] = cpu_baseline(frames, tpls, H.Camera.from_buffer_copy(bytes(camera)))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

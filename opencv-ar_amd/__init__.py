@@ -100,6 +100,47 @@ def hip_lib():
     return _hip
 
 
+_host = None
+
+
+def host_lib():
+    """The host C++ mirror of the reference's public API (libopencv-ar.so: cvarLoadTemplateTag, cvarReadCamera, ...)."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise OcvarError(f"{HOST_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        hip_lib()   # libopencv-ar.so links against the HIP library: same runtime-ordering rule
+        lib = C.CDLL(HOST_LIB)
+        lib.cvarLoadTemplateTag.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        lib.cvarReadCamera.argtypes = [C.c_char_p, C.c_void_p]
+        lib.cvarCameraScale.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _host = lib
+    return _host
+
+
+TEMPLATE_DIR = os.path.join(os.path.dirname(_HERE), "assets", "templates")
+
+
+def load_templates(paths, scale=0.01):
+    """cvarLoadTemplateTag (reference opencvar.cpp:284-321) on each PNG -> list of Template."""
+    out = []
+    for path in paths:
+        t = Template()
+        if host_lib().cvarLoadTemplateTag(C.byref(t), os.fsencode(path), scale) != 1:
+            raise OcvarError(f"cvarLoadTemplateTag failed for {path}")
+        out.append(t)
+    return out
+
+
+def default_camera(width, height, filename=None):
+    """cvarReadCamera(filename or NULL) then cvarCameraScale(width, height) (opencvar.cpp:37-102)."""
+    cam = Camera()
+    if host_lib().cvarReadCamera(os.fsencode(filename) if filename else None, C.byref(cam)) != 1:
+        raise OcvarError(f"cvarReadCamera failed for {filename}")
+    host_lib().cvarCameraScale(C.byref(cam), width, height)
+    return cam
+
+
 def _ptr(a):
     return C.c_void_p(a.ctypes.data) if a is not None else None
 

@@ -10,9 +10,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 cfg = H.synth_config(3)
 base = np.stack([H.synth_frame(cfg, i)[0] for i in range(16)])
 frames = np.concatenate([base] * (B // 16))
-tpls, cam = H.oracle_templates(), H.oracle_camera(cfg.width, cfg.height)
+tpls = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, n + ".png") for n in H.TEMPLATE_ORDER])
+cam = oa.default_camera(cfg.width, cfg.height)
 det = oa.Detector(cfg.width, cfg.height, max_batch=64)
-det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls]); det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+det.set_templates(tpls); det.set_camera(cam)
 for grey in (False, True):
     det.detect_host(frames.copy(), grey_in_place=grey)
     work = frames.copy()

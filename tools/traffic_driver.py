@@ -8,9 +8,10 @@ import opencv_ar_amd as oa
 B, CAL = 64, 1 << 28
 cfg = H.synth_config(3)
 frames = np.stack([H.synth_frame(cfg, i)[0] for i in range(16)] * (B // 16))
-tpls, cam = H.oracle_templates(), H.oracle_camera(cfg.width, cfg.height)
+tpls = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, n + ".png") for n in H.TEMPLATE_ORDER])
+cam = oa.default_camera(cfg.width, cfg.height)
 det = oa.Detector(cfg.width, cfg.height, max_batch=B)
-det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls]); det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+det.set_templates(tpls); det.set_camera(cam)
 assert oa.hip_lib().ocvar_hip_debug_calibrate(det._ctx, CAL) == 0
 d = torch.from_numpy(frames).cuda()
 for _ in range(4):
