@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(frames, tpls, cam, budget_s=12.0):
+def cpu_baseline(np.concatenate([base] * ((256 + uniq - 1) // uniq)), tpls, cam, budget_s=12.0):
     """The oracle (CPU restatement of the reference path, oracle/) timed on a bounded sample of the same frames,
     single thread -- the reference is single-threaded.  Reported beside the GPU number, never part of it."""
     import helpers as H
@@ -73,7 +73,6 @@ def main():
     uniq = max(1, min(args.unique, B))
     # frame index space is sharded by frame: rank r owns frames r, r+world, ...
     base = np.stack([H.synth_frame(cfg, S.frame_of(rank, world, i), names)[0] for i in range(uniq)])
-    frames = np.concatenate([base] * ((B + uniq - 1) // uniq))[:B]
     # setup side through the product's own host library (cvarLoadTemplateTag on the PNGs, cvarReadCamera(NULL) +
     # cvarCameraScale); the oracle is only touched by the cpu_baseline leg below
     tpl_list = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, n + ".png") for n in (names or H.TEMPLATE_ORDER)])
@@ -91,7 +90,8 @@ def main():
         dets.append(det)
         streams.append(torch.cuda.Stream())
     det = dets[0]
-    d_frames = torch.from_numpy(frames).cuda()
+    # the batch is the distinct frames tiled, built on the device (the host only ever holds `uniq` frames)
+    d_frames = torch.from_numpy(base).cuda().repeat((B + uniq - 1) // uniq, 1, 1, 1)[:B].contiguous()
     frame_bytes = W * Hh * 3
     d_res = torch.empty(S.block_bytes(B), dtype=torch.uint8, device="cuda")
     nbytes_m = B * S.MAX_MARKERS * S.MARKER_BYTES
@@ -229,7 +229,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             tpls = (H.Template * len(tpl_list))(*[H.Template.from_buffer_copy(bytes(t)) for t in tpl_list])
-            out["cpu_baseline"] = cpu_baseline(frames, tpls, H.Camera.from_buffer_copy(bytes(camera)))
+            out["cpu_baseline"] = cpu_baseline(np.concatenate([base] * ((256 + uniq - 1) // uniq)), tpls, H.Camera.from_buffer_copy(bytes(camera)))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
