@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(np.concatenate([base] * ((256 + uniq - 1) // uniq)), tpls, cam, budget_s=12.0):
+def cpu_baseline(frames, tpls, cam, budget_s=12.0):
     """The oracle (CPU restatement of the reference path, oracle/) timed on a bounded sample of the same frames,
     single thread -- the reference is single-threaded.  Reported beside the GPU number, never part of it."""
     import helpers as H
