@@ -206,7 +206,7 @@ def main():
             "metric": "frames/sec at 1920x1080, 16 markers/frame; 1/2/4/8 MI355X", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / K, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"configs[2]: {W}x{Hh}, {cfg.grid_x * cfg.grid_y} markers/frame, templates "
+            "config": {"workload": f"configs[{args.config - 1}]: {W}x{Hh}, {cfg.grid_x * cfg.grid_y} markers/frame, templates "
                                    f"{'2x2' if names else '2x2/3x3/4x4 x 4 rotations'}, batch {B} frames/GPU/step "
                                    f"({uniq} distinct) in {NS} stream(s), stateless", "frames_per_step_per_gpu": B, "streams": NS,
                        "parallelism": f"frame-sharded x{world}" + (", RCCL gather of CvarMarker arrays" if world > 1 else "")},
