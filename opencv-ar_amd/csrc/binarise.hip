@@ -5,8 +5,8 @@
 // also the BGR2GRAY of cvarArMultRegistration (opencvar.cpp:624-627) -- and the local part of cvFindContours
 // (opencvar.cpp:183-184): zeroing the 1-px frame and spotting where a border can begin.
 //
-// "Wave march": one 64-lane wavefront owns a strip of 256 columns (4 pixels per lane: 224 output columns + a
-// 16-column halo on each side) and walks down a chunk of rows.  Everything vertical lives in registers as
+// "Wave march": one 64-lane wavefront owns a strip of 256 columns (4 pixels per lane: 240 output columns + an
+// 8-column halo on each side) and walks down a chunk of rows.  Everything vertical lives in registers as
 // sliding windows (5 rows of the horizontal pyrDown sums, 3 rows of the horizontally up-sampled pyramid,
 // 7 rows of the horizontal Gaussian sums, 3 rows of threshold bits); everything horizontal is a 4-pixel packed
 // word handed to the neighbour lane.  No LDS allocation, no workgroup barrier, one coalesced dword load/store
@@ -18,7 +18,14 @@
 
 namespace ocvar {
 
-constexpr int SV = MARCH_STRIP;  // output columns per strip (lanes 4..59)
+constexpr int SV = MARCH_STRIP;  // output columns per strip
+// Halo: an output pixel's mask depends on source pixels up to 9 columns to its left and 10 to its right (mask 1 (+1 for
+// the start test), 7-tap Gaussian 3, pyrUp 3, pyrDown 2), but the stages exchange whole lanes: following the chain lane
+// by lane, the first output lane needs the grey of 2 lanes to its left and the last one of 2 lanes to its right -- a third
+// lane on the right would only serve the start filter's "row above at x+2" bit of the strip's last column, which is
+// dropped instead (the filter is a necessary condition: without it that column merely yields a few more plausible starts).
+// 240 output columns: 8 strips across 1920, 16 across 3840.
+constexpr int HL = MARCH_HALO_L, HR = MARCH_HALO_R;
 
 // A value that is the same in all lanes of the wave, moved to an SGPR.  The work-unit index comes from threadIdx.x >> 6,
 // which the compiler must treat as per-lane: without this every row counter of the march lives in a VGPR, every loop
@@ -72,17 +79,17 @@ template <bool BGR>
 __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int sh, int strip, int Y0, int Y1, const MarchOut& o,
                            unsigned* stage) {
     const int lane = threadIdx.x & 63;
-    const int XS = strip * SV - 16;
+    const int XS = strip * SV - 4 * HL;
     const int c0 = XS + 4 * lane;
     const int pw = sw >> 1, ph_ = sh >> 1;
     const int k0 = c0 >> 1;  // pyramid column of the lane's first pyramid sample (c0 is a multiple of 4)
-    const bool out_lane = lane >= 4 && lane < 60 && c0 < sw;
+    const bool out_lane = lane >= HL && lane < 64 - HR && c0 < sw;
     const bool needed = c0 + 3 >= -16 && c0 < sw + 16;  // beyond every halo: never consumed
     const bool fast = c0 >= 0 && c0 + 3 < sw;
     const bool aligned = BGR ? ((src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) : true;
-    const bool left_edge = strip == 0;             // lanes 0..3 hold virtual columns -16..-1
+    const bool left_edge = strip == 0;             // lanes 0..HL-1 hold virtual columns -4*HL..-1
     const int L1 = (sw - 1 - XS) >> 2, j1 = (sw - 1 - XS) & 3;  // lane / byte of column sw-1
-    const bool right_edge = L1 <= 61;              // some needed lane holds columns >= sw
+    const bool right_edge = L1 <= 63;              // some lane of the wave holds columns >= sw
     const bool gray_dword = o.gray && (o.gray_stride & 3) == 0 && c0 + 3 < sw;
     // reflected source columns of the lanes that straddle an image edge (BORDER_REFLECT_101)
     int xr0 = 0, xr1 = 0, xr2 = 0, xr3 = 0;
@@ -96,6 +103,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     const unsigned src_off = fast ? (unsigned)(c0 * (BGR ? 3 : 1)) : 0u;
     const unsigned out_off = out_lane ? (unsigned)c0 : 0u;
     const unsigned nbr_off = out_lane ? nbr_col_off(c0) : 0u;
+    const unsigned right_bits = lane == 63 - HR ? 0x202020u : 0x202060u;   // the last output lane's x+2 bit (row above) is not computed
     unsigned colmask = 0;  // which of the lane's 4 columns lie inside cvFindContours' zeroed frame
     for (int j = 0; j < 4; j++) colmask |= (c0 + j >= 1 && c0 + j <= sw - 2) ? (1u << j) : 0u;
     unsigned pxmask = 0;   // bit 8j: the lane's pixel j is an output pixel of this strip
@@ -232,8 +240,8 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                 if (left_edge || right_edge) {
                     unsigned U4 = as_u32(Ue) | (as_u32(Uo) << 8);
                     if (left_edge) {
-                        const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)U4, 4) & 255u;
-                        if (lane < 4) U4 = e * 0x01010101u;
+                        const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)U4, HL) & 255u;   // column 0
+                        if (lane < HL) U4 = e * 0x01010101u;
                     }
                     if (right_edge) {
                         const unsigned e = byte_of((unsigned)__builtin_amdgcn_readlane((int)U4, L1 < 0 ? 0 : L1), j1);
@@ -287,7 +295,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                     // (columns c0-1 .. c0+4) with the edge bits of the neighbour lanes; a multiplication by 0x204081 lays
                     // copies shifted by 7, 14, 21 side by side so that byte p holds (window >> p): bits 0,1,2 = x-1, x, x+1 of
                     // pixel p.  The row above goes through a bit reversal because directions run counter-clockwise.
-                    const unsigned Wn = binw | ((up1(binw) >> 4) & 0x010101u) | ((down1(binw) << 4) & 0x202060u);   // row above: one more column (x+2 of pixel 3)
+                    const unsigned Wn = binw | ((up1(binw) >> 4) & 0x010101u) | ((down1(binw) << 4) & right_bits);   // row above: one more column (x+2 of pixel 3)
                     const unsigned Ms = __umul24((Wn >> 8) & 0x3fu, 0x204081u);
                     const unsigned Bs = __umul24((Wn >> 11) & (0x3fu << 5), 0x204081u) & 0xe0e0e0e0u;   // SW S SE at bits 5..7
                     const unsigned As = __umul24(__builtin_bitreverse32(Wn) >> 26, 0x204081u) & 0x07070707u;   // byte 3-p: NE, N, NW of pixel p

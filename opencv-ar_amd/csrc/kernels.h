@@ -11,7 +11,8 @@ namespace ocvar {
 constexpr int MAXQ = OCVAR_MAX_QUADS;      // frame-pass quads kept per frame
 constexpr int MAXM = OCVAR_MAX_MARKERS;    // markers kept per frame (tracked + new)
 constexpr int MAXT = OCVAR_MAX_TEMPLATES;
-constexpr int MARCH_STRIP = 224;           // output columns of one wave's strip in the binarise kernel (256 loaded)
+constexpr int MARCH_HALO_L = 2, MARCH_HALO_R = 2;   // halo lanes (4 pixels each) left / right of a strip's output lanes
+constexpr int MARCH_STRIP = 4 * (64 - MARCH_HALO_L - MARCH_HALO_R);   // 240 output columns of one wave's strip in the binarise kernel (256 loaded)
 constexpr int MARCH_CROP_ROWS = 256;       // rows per work unit in the crop pass (even)
 constexpr int MARCH_STAGE = 512;           // border starts a wave stages in LDS between two appends to the global list
 constexpr int BACK_STEPS = 32;
