@@ -91,7 +91,7 @@ def main():
         streams.append(torch.cuda.Stream())
     det = dets[0]
     # the batch is the distinct frames tiled, built on the device (the host only ever holds `uniq` frames)
-    d_frames = torch.from_numpy(base).cuda().repeat((B + uniq - 1) # uniq, 1, 1, 1)[:B].contiguous()
+    d_frames = torch.from_numpy(base).cuda().repeat((B + uniq - 1) // uniq, 1, 1, 1)[:B].contiguous()
     torch.cuda.synchronize()   # the detectors run on their own streams: the tiling copy (torch's stream) must have finished
     frame_bytes = W * Hh * 3
     d_res = torch.empty(S.block_bytes(B), dtype=torch.uint8, device="cuda")
