@@ -94,7 +94,7 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     if ((rc = dev_alloc(c, &w.cands_frame, (size_t)w.cap_frame_cands))) return rc;
     if ((rc = dev_alloc(c, &w.cands_crop, (size_t)w.cap_crop_cands))) return rc;
     if ((rc = dev_alloc(c, &w.pool, (size_t)w.cap_pool_ints))) return rc;
-    if ((rc = dev_alloc(c, &w.slab, (size_t)MID_BLOCKS * 256 * (4 * SLAB_PTS + 4)))) return rc;
+    if ((rc = dev_alloc(c, &w.slab, (size_t)MID_BLOCKS_MAX * 256 * (4 * SLAB_PTS + 4)))) return rc;
     if ((rc = dev_alloc(c, &w.slab3, (size_t)LONG_BLOCKS_MAX * 4 * (4 * SLAB3_PTS + 4)))) return rc;
     w.cap_long = (int)std::min<size_t>(B * 4096, (size_t)1 << 28);
     if ((rc = dev_alloc(c, &w.mid_frame, (size_t)w.cap_long))) return rc;
@@ -203,6 +203,8 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     w.ns = (w.sw + 15) & ~15;
     w.n_frames = n_frames;
     w.mid_steps = std::getenv("OCVAR_MID_STEPS") ? std::atoi(std::getenv("OCVAR_MID_STEPS")) : MID_STEPS;
+    w.mid_blocks = std::getenv("OCVAR_MID_BLOCKS") ? std::atoi(std::getenv("OCVAR_MID_BLOCKS")) : MID_BLOCKS_MAX;
+    if (w.mid_blocks < 1 || w.mid_blocks > MID_BLOCKS_MAX) w.mid_blocks = MID_BLOCKS_MAX;
     w.long_blocks = std::getenv("OCVAR_LONG_BLOCKS") ? std::atoi(std::getenv("OCVAR_LONG_BLOCKS")) : LONG_BLOCKS_MAX;
     if (w.long_blocks < 1 || w.long_blocks > LONG_BLOCKS_MAX) w.long_blocks = LONG_BLOCKS_MAX;
     w.frame_strips = (w.sw + MARCH_STRIP - 1) / MARCH_STRIP;

@@ -751,10 +751,10 @@ void launch_follow_crops(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL((follow_kernel<true, 1>), dim3(1024), dim3(256), 0, stream, ws);
 }
 void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL((follow_kernel<false, 2>), dim3(MID_BLOCKS), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL((follow_kernel<false, 2>), dim3(ws.mid_blocks), dim3(256), 0, stream, ws);
 }
 void launch_follow_mid_crops(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL((follow_kernel<true, 2>), dim3(MID_BLOCKS), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL((follow_kernel<true, 2>), dim3(ws.mid_blocks), dim3(256), 0, stream, ws);
 }
 void launch_follow_long_frames(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_long_kernel<false>, dim3(ws.long_blocks), dim3(256), 0, stream, ws);

@@ -20,7 +20,7 @@ constexpr int PRE_STEPS = 8;               // steps every plausible start gets b
 constexpr int SHORT_STEPS = 96;            // step budget of follower tier 1 (every plausible start, one lane each)
 constexpr int MID_STEPS = 1536;            // step budget of tier 2 (borders that outlived tier 1, one lane each); the rest: tier 3, one wave each
 constexpr int SLAB_PTS = 1024;             // points a tier-2 lane can keep in its private slab (no second follow needed below that)
-constexpr int MID_BLOCKS = 512;            // tier-2 grid (x256 threads, one slab each)
+constexpr int MID_BLOCKS_MAX = 512;        // tier-2 grid limit (x256 threads, one slab each)
 constexpr int SLAB3_PTS = 8192;            // points a tier-3 wave can keep in its slab
 constexpr int LONG_BLOCKS_MAX = 1024;      // tier-3 grid limit (x4 waves, one slab each)
 constexpr int TILE = 64;                   // side of the LDS tile the wave-per-border follower walks in             // backward look of an outer start before it follows its border
@@ -51,7 +51,7 @@ struct Workspace {
     long long cap_pool_ints, cap_crop_pixels;
     // per batch geometry
     int W, H, sw, sh, ns, n_frames, n_templates;   // ns: row stride of a neighbour-mask plane = sw rounded up to 4
-    int mid_steps, long_blocks;  // tuning (env OCVAR_MID_STEPS / OCVAR_LONG_BLOCKS): tier-2 step budget, tier-3 grid
+    int mid_steps, mid_blocks, long_blocks;  // tuning (env OCVAR_MID_STEPS / OCVAR_MID_BLOCKS / OCVAR_LONG_BLOCKS): tier-2 step budget and grid, tier-3 grid
     int frame_strips, frame_chunks, frame_chunk_rows;  // binarise work decomposition of a frame
     // device buffers
     uint8_t* gray;          // [B][H][W]
@@ -65,7 +65,7 @@ struct Workspace {
     StartCand* long_crop;
     int cap_long;
     int* pool;              // points + DP stacks
-    int* slab;              // [MID_BLOCKS*256][4*SLAB_PTS+4] private point + stack space of the tier-2 lanes
+    int* slab;              // [MID_BLOCKS_MAX*256][4*SLAB_PTS+4] private point + stack space of the tier-2 lanes
     int* slab3;             // [LONG_BLOCKS_MAX*4][4*SLAB3_PTS+4] point + stack space of the tier-3 waves
     QuadRec* quads_frame;   // [B][MAXQ] unordered
     int* n_quads_frame;     // [B]
