@@ -310,7 +310,7 @@ __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand
         // the border barely turned in SHORT_STEPS steps (an image-sized straight border would only burn tier 2's whole
         // budget before getting there anyway).
         if (!c.is_hole && earlier_start_behind(pl.nbr, pl.ns, pl.plane, c.pos, 0, BACK_STEPS)) return 0;
-        const LeanTrace lt = trace_lean(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
+        const LeanTrace lt = trace_flat(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
         if (lt.status == TRACE_OVERRUN) return lt.npts <= 2 ? 2 : 1;
         if (lt.status != TRACE_OK || lt.npts < 4) return 0;
         return 1;
@@ -319,7 +319,7 @@ __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand
         // tier 2 stores the points while it follows (lean loop, private slab): a border that fits needs no second
         // follow, and its statistics come from the stored points
         int* slab = ws.slab + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (4 * SLAB_PTS + 4);
-        const LeanTrace lt = trace_lean(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, slab, SLAB_PTS, BUDGET);
+        const LeanTrace lt = trace_flat(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, slab, SLAB_PTS, BUDGET);
         if (lt.status == TRACE_OVERRUN) return 1;  // budget exhausted: a longer border
         if (lt.status != TRACE_OK || lt.npts < 4) return false;
         if (lt.npts <= SLAB_PTS) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
                     cc = cands[idx];
                     const PlaneRef pl = plane_of<CROP>(ws, cc.roi);
                     if (cc.pos > 0 && cc.pos < pl.plane)
-                        alive = trace_lean(pl.nbr, pl.ns, pl.plane, cc.pos, cc.is_hole, nullptr, 0, PRE_STEPS).status == TRACE_OVERRUN;
+                        alive = trace_flat(pl.nbr, pl.ns, pl.plane, cc.pos, cc.is_hole, nullptr, 0, PRE_STEPS).status == TRACE_OVERRUN;
                 }
                 const unsigned long long mask = __ballot(alive);
                 if (alive) wqueue[wave][queued + __popcll(mask & ((1ull << lane) - 1ull))] = cc;

@@ -288,6 +288,68 @@ OCVAR_HD LeanTrace trace_lean(const uint8_t* nbr, int ns, int plane, int cpos, i
     return r;
 }
 
+// trace_lean with a straight-line loop body.  On the GPU every `if` inside a lane-divergent loop costs an EXEC-mask
+// save/restore and a branch per wave and step, and a memory operation inside a branch makes the compiler wait for all
+// outstanding ones; here the three ways a walk ends (not the border's first position, closed, left the plane) and the
+// emission of a corner point are predicates, the load of the next mask and the store of the point are unconditional
+// (a lane that ends re-reads its own pixel; a step without a point stores into the scratch slot behind the last
+// point), and the only control flow is the loop itself.  Same results as trace_lean, step for step.
+// out must hold max_pts + 1 points; with max_pts == 0 nothing is stored (out may be null).
+OCVAR_HD LeanTrace trace_flat(const uint8_t* nbr, int ns, int plane, int cpos, int is_hole, int* out, int max_pts, int max_steps) {
+    LeanTrace r;
+    r.status = TRACE_OK;
+    r.npts = 0;
+    r.steps = 0;
+    const int i0 = cpos - is_hole;
+    int x = i0 % ns, y = i0 / ns;
+    unsigned m = nbr[nbr_addr(x, y, ns)];
+    if (m == 0) {
+        r.status = TRACE_SINGLE;
+        r.npts = 1;
+        return r;
+    }
+    int s = first_cw(m, (is_hole ? 0 : 4) - 1);
+    const int i1 = i0 + mul_small(step_dy(s), ns) + step_dx(s);
+    int idx = i0;
+    int prev_s = s ^ 4;
+    int npts = 0, step = 0;
+    int status = -1;   // running
+    while (status < 0) {
+        const int from = (s + 1) & 7;
+        const int t = __builtin_ctz(((m * 0x101u) >> from) & 0xffu);   // zero neighbours passed before the next border pixel
+        const int e = (from + t) & 7;                                   // exit direction
+        const unsigned passed = ((((1u << t) - 1u) * 0x101u) << from) >> 8;   // 8-bit rotate of t ones to position `from`
+        const bool budget = step >= max_steps;
+        const bool nf = !budget && (((passed & 0x10u) != 0 && idx < cpos) || ((passed & 1u) != 0 && idx + 1 < cpos));
+        const int dx = step_dx(e), dy = step_dy(e);
+        const int nidx = idx + mul_small(dy, ns) + dx;
+        const bool closes = !budget && !nf && nidx == i0 && idx == i1;
+        const bool oob = !budget && !nf && !closes && (unsigned)nidx >= (unsigned)plane;
+        const bool go = !(budget || nf || closes || oob);
+        const bool emit = e != prev_s && (go || closes);   // CHAIN_APPROX_SIMPLE: a point wherever the direction changes
+        const int lx = go ? x + dx : x, ly = go ? y + dy : y;
+        const unsigned m4 = nbr[nbr_addr(lx, ly, ns)];
+        if (max_pts > 0) {
+            const int slot = (emit && npts < max_pts) ? npts : max_pts;
+            out[2 * slot] = x;
+            out[2 * slot + 1] = y;
+        }
+        npts += emit ? 1 : 0;
+        status = budget ? (int)TRACE_OVERRUN : nf ? (int)TRACE_NOT_FIRST : closes ? (int)TRACE_OK : (oob || m4 == 0) ? (int)TRACE_OVERRUN : -1;
+        step += go ? 1 : 0;
+        x = lx;
+        y = ly;
+        idx = go ? nidx : idx;
+        prev_s = go ? e : prev_s;
+        m = m4;
+        s = go ? (e ^ 4) : s;
+    }
+    r.status = status;
+    r.npts = npts;
+    r.steps = step;
+    return r;
+}
+
 // cvArcLength(closed) and the bounding box of stored contour points -> the TraceStats the filters expect
 OCVAR_HD TraceStats stats_of_points(const int* pts, int n) {
     TraceStats st;

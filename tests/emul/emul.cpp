@@ -54,7 +54,8 @@ extern "C" int emul_find_contours(const uint8_t* bin, int w, int h, int* pts, in
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), w, w * h, y * w + x, 0, g_back)) { g_back_drops++; continue; }
             TraceStats st;
             if (g_lean) {
-                LeanTrace lt = trace_lean(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, buf.data(), (int)buf.size() / 2 - 1, 4 * w * h + 16);
+                LeanTrace lt = g_lean == 2 ? trace_flat(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, buf.data(), (int)buf.size() / 2 - 1, 4 * w * h + 16)
+                                           : trace_lean(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, buf.data(), (int)buf.size() / 2 - 1, 4 * w * h + 16);
                 st.status = lt.status;
                 st.npts = lt.npts;
                 if (lt.status == TRACE_SINGLE) { buf[0] = x; buf[1] = y; }

@@ -32,16 +32,17 @@ def test_parallel_border_starts_equal_sequential_scan(emul):
     rng = np.random.default_rng(1)
     for trial in range(300):
         emul.emul_set_run(trial & 1)  # with and without straight-run skipping
-        emul.emul_set_lean((trial >> 1) & 1)  # and through the lean follower of tiers 2/3
+        emul.emul_set_lean((trial >> 1) % 3)  # 1: the lean follower, 2: its straight-line form (tiers 1/2 on the GPU)
         h, w = int(rng.integers(3, 40)), int(rng.integers(3, 40))
         dens = rng.choice([0.1, 0.3, 0.5, 0.6, 0.7, 0.9])
         b = (rng.random((h, w)) < dens).astype(np.uint8) * 255
         if trial % 5 == 0:
             b = np.kron((rng.random((h // 3 + 1, w // 3 + 1)) < dens).astype(np.uint8), np.ones((3, 3), np.uint8))[:h, :w] * 255
         assert same_contours(H.oracle_contours(b), emul_contours(emul, b)), trial
-    emul.emul_set_lean(1)
     b = (rng.random((240, 320)) < 0.55).astype(np.uint8) * 255
-    assert same_contours(H.oracle_contours(b), emul_contours(emul, b))
+    for lean in (1, 2):
+        emul.emul_set_lean(lean)
+        assert same_contours(H.oracle_contours(b), emul_contours(emul, b))
     emul.emul_set_lean(0)
 
 
