@@ -188,6 +188,36 @@ def test_empty_and_noise_frames(oa):
     assert counts[0] == 0
 
 
+def test_smallest_frames_and_markers_cut_by_the_frame_edge(oa):
+    """Edge cases: the smallest frames the entry point accepts (16x16, 17x33: one strip, one chunk, every border rule
+    at once) and views of a synthetic frame whose edges cut through markers (quads touching the zeroed 1-px frame,
+    cvarFindSquares' first-vertex border rule opencvar.cpp:204-206, crops clipped by cvSetImageROI)."""
+    rng = np.random.default_rng(5)
+    for (w, h) in ((16, 16), (17, 33), (40, 18)):
+        cfg = H.synth_config(2, width=w, height=h)
+        det, tpls, cam = make_detector(oa, cfg, ["2x2-01"], 2)
+        frames = np.stack([np.repeat(rng.integers(0, 256, (h, w, 1), np.uint8), 3, axis=2),
+                           np.kron(rng.integers(0, 2, ((h + 3) // 4, (w + 3) // 4, 1), np.uint8) * 255, np.ones((4, 4, 3), np.uint8))[:h, :w]])
+        frames = np.ascontiguousarray(frames)
+        markers, counts = det.detect_host(frames.copy())
+        for f in range(2):
+            check_frame(det, f, frames[f], tpls, cam, markers, counts)
+    cfg = H.synth_config(2)
+    full, truth = H.synth_frame(cfg, 1, ["2x2-01"])
+    c = truth[0]["corner"]
+    cx, cy = int(c[:, 0].mean()), int(c[:, 1].mean())
+    views = [full[:, cx:], full[cy:, :], full[: cy + 3, : cx + 5], full[max(0, cy - 150):, max(0, cx - 150): cx + 9]]
+    for v in views:
+        v = np.ascontiguousarray(v)
+        h, w = v.shape[:2]
+        if w < 16 or h < 16:
+            continue
+        cfgv = H.synth_config(2, width=w, height=h)
+        det, tpls, cam = make_detector(oa, cfgv, ["2x2-01"], 1)
+        markers, counts = det.detect_host(v[None].copy())
+        check_frame(det, 0, v, tpls, cam, markers, counts)
+
+
 def test_find_squares_entry_matches_oracle_on_crops(oa):
     cfg = H.synth_config(3)
     det, tpls, cam = make_detector(oa, cfg, None, 1)
