@@ -209,12 +209,13 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     if (w.long_blocks < 1 || w.long_blocks > LONG_BLOCKS_MAX) w.long_blocks = LONG_BLOCKS_MAX;
     w.frame_strips = (w.sw + MARCH_STRIP - 1) / MARCH_STRIP;
     {   // rows per binarise work unit: even, chunks of equal size.  Every chunk re-reads ~12 halo rows, so chunks are as
-        // tall as the batch allows while the launch still has >= 16K waves; never < ~128 rows.  (Measured: choosing the
+        // tall as the batch allows while the launch still has >= 64K waves (env OCVAR_MIN_UNITS); never < ~128 rows.  (Measured: choosing the
         // count to fill whole "rounds" of resident waves is no better -- the kernel is issue-bound, not round-bound --
         // and three 360-row chunks per 1080p frame were 20 % slower than eight 136-row ones at 256 frames.)
         int chunks = (w.sh + 64) / 128;
         if (chunks < 1) chunks = 1;
-        while (chunks > 1 && (long long)w.frame_strips * (chunks / 2) * n_frames >= 16384) chunks /= 2;
+        static const long long min_units = std::getenv("OCVAR_MIN_UNITS") ? std::atoll(std::getenv("OCVAR_MIN_UNITS")) : 65536;
+        while (chunks > 1 && (long long)w.frame_strips * (chunks / 2) * n_frames >= min_units) chunks /= 2;
         int rows = (w.sh + chunks - 1) / chunks;
         rows = (rows + 1) & ~1;
         w.frame_chunk_rows = rows;
