@@ -61,11 +61,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
-    torch.cuda.set_device(local_rank)
+    # OCVAR_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks (ranks share devices,
+    # the gather is staged through the host); the driver's runs use the default: one GPU per rank, RCCL.
+    backend = os.environ.get("OCVAR_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     cfg = H.synth_config(args.config)
     names = ["2x2-01"] if args.config in (1, 2) else None
@@ -84,7 +91,7 @@ def main():
     offs = np.concatenate([[0], np.cumsum(sub)]).astype(int)
     dets, streams = [], []
     for i in range(NS):
-        det = oa.Detector(W, Hh, max_batch=sub[i], device=local_rank)
+        det = oa.Detector(W, Hh, max_batch=sub[i], device=device_index)
         det.set_templates(tpl_list)
         det.set_camera(camera)
         dets.append(det)
@@ -94,7 +101,9 @@ def main():
     d_frames = torch.from_numpy(base).cuda().repeat((B + uniq - 1) // uniq, 1, 1, 1)[:B].contiguous()
     torch.cuda.synchronize()   # the detectors run on their own streams: the tiling copy (torch's stream) must have finished
     frame_bytes = W * Hh * 3
-    d_res = torch.empty(S.block_bytes(B), dtype=torch.uint8, device="cuda")
+    # result blocks for the RCCL gather, double-buffered: launches enqueued during step k write buffer (k+1)%2 while the
+    # gather at the end of step k reads buffer k%2 (filled by the launches that were collected during step k)
+    d_res = [torch.zeros(S.block_bytes(B), dtype=torch.uint8, device="cuda") for _ in range(2)]
     nbytes_m = B * S.MAX_MARKERS * S.MARKER_BYTES
 
     # K steps as a software pipeline.  Every context runs its sub-batches back to back on its own stream; the contexts are
@@ -107,11 +116,11 @@ def main():
     frames_done = [0]
     last = {}
 
-    def enqueue(i, n):
+    def enqueue(i, n, buf):
         dets[i].enqueue_device(d_frames.data_ptr() + int(offs[i]) * frame_bytes, W, Hh, n, stream=streams[i].cuda_stream)
         if world > 1:
-            dets[i].results_to_device(d_res.data_ptr() + int(offs[i]) * S.MAX_MARKERS * S.MARKER_BYTES,
-                                      d_res.data_ptr() + nbytes_m + 4 * int(offs[i]), streams[i].cuda_stream)
+            dets[i].results_to_device(d_res[buf].data_ptr() + int(offs[i]) * S.MAX_MARKERS * S.MARKER_BYTES,
+                                      d_res[buf].data_ptr() + nbytes_m + 4 * int(offs[i]), streams[i].cuda_stream)
         last[i] = n
 
     def collect(i, timed):
@@ -126,17 +135,17 @@ def main():
         first = [max(1, ((i + 1) * sub[i]) // NS) for i in range(NS)]
         parts = [None] * NS
         for i in range(NS):
-            enqueue(i, first[i])
+            enqueue(i, first[i], 0)
         for k in range(K):
             for i in range(NS):
                 parts[i] = collect(i, timed)
                 n = sub[i] if k < K - 1 else sub[i] - first[i]
                 if n > 0:
-                    enqueue(i, n)
+                    enqueue(i, n, (k + 1) % 2)
                 else:
                     last.pop(i)
-            if world > 1:   # one gather of the ranks' result blocks per step (all of the step's launches are complete)
-                blocks = S.gather_blocks(d_res, rank, world, dist)
+            if world > 1:   # one gather of the ranks' result blocks per step (the launches that filled this buffer are complete)
+                blocks = S.gather_blocks(d_res[k % 2], rank, world, dist)
                 torch.cuda.current_stream().synchronize()
                 if rank == 0 and not timed:
                     S.unpack(blocks, B, oa.MARKER_DTYPE)  # warm-up only: checks the gathered blocks decode
@@ -159,7 +168,7 @@ def main():
     dt = time.perf_counter() - t0
     assert frames_done[0] == B * args.steps, (frames_done[0], B, args.steps)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -210,7 +219,7 @@ def main():
             "config": {"workload": f"configs[{args.config - 1}]: {W}x{Hh}, {cfg.grid_x * cfg.grid_y} markers/frame, templates "
                                    f"{'2x2' if names else '2x2/3x3/4x4 x 4 rotations'}, batch {B} frames/GPU/step "
                                    f"({uniq} distinct) in {NS} stream(s), stateless", "frames_per_step_per_gpu": B, "streams": NS,
-                       "parallelism": f"frame-sharded x{world}" + (", RCCL gather of CvarMarker arrays" if world > 1 else "")},
+                       "parallelism": f"frame-sharded x{world}" + ((", RCCL gather of CvarMarker arrays" if backend == "nccl" else f", {backend} rehearsal of the gather (ranks share devices)") if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "launch_ms": round(float(stage_ms[dom[1]]), 4), "alg_bytes_per_launch": round(dom[2])},

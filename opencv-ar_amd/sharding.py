@@ -23,6 +23,8 @@ def gather_blocks(local_block, rank, world, dist=None):
     tensors (rank order), elsewhere None."""
     if world == 1:
         return [local_block]
+    if local_block.is_cuda and dist.get_backend() == "gloo":   # rehearsal of the N > 1 flow without RCCL: stage through the host
+        local_block = local_block.cpu()
     out = [torch.empty_like(local_block) for _ in range(world)] if rank == 0 else None
     dist.gather(local_block, out, dst=0)
     return out
