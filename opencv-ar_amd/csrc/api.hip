@@ -85,7 +85,7 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     w.cap_crop_rois = (int)(B * MAXQ);
     w.cap_crop_tiles = (int)std::min<size_t>(B * 4096, (size_t)1 << 30);
     w.cap_crop_quads = (int)(B * MAXQ * 4);
-    w.cap_pool_ints = (long long)B * (1 << 20);
+    w.cap_pool_ints = (long long)B * (1 << 18) + (1 << 20);   // only tier-2 borders with more corner points than a lane slab holds land here
     w.cap_crop_pixels = (long long)(2 * B * (size_t)(max_width + 16) * (max_height + 8));
     int rc;
     if ((rc = dev_alloc(c, &w.gray, B * WH))) return rc;
