@@ -142,6 +142,67 @@ def test_camera_file_reader(host, tmp_path, text, ext):
     assert host.cvarReadCamera(str(bad).encode(), C.byref(cam)) == 0
 
 
+class _Pt(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+class _Rect(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("width", C.c_int), ("height", C.c_int)]
+
+
+def test_geometry_helpers_follow_the_reference(host):
+    """cvarSquare2Rect (opencvar.cpp:546-562: float->int truncation at every assignment), cvarRotSquare (464-501:
+    src[(rot-1+i)%4] = old[i]), cvarTrack (592-617: all four corners within 20 px under some cyclic shift, pt1 replaced),
+    cvarSquare (437-458), cvarReverseSquare, cvarSquareToMatrix against the oracle's pose."""
+    rng = np.random.default_rng(3)
+    host.cvarSquare2Rect.restype = _Rect
+    host.cvarSquare2Rect.argtypes = [C.c_void_p]
+    host.cvarTrack.argtypes = [C.c_void_p, C.c_void_p]
+    host.cvarRotSquare.argtypes = [C.c_void_p, C.c_int]
+    for _ in range(50):
+        pts = (rng.random((4, 2)) * 700 - 30).astype(np.float32)
+        arr = (_Pt * 4)(*[_Pt(float(a), float(b)) for a, b in pts])
+        r = host.cvarSquare2Rect(arr)
+        x, y, x2, y2 = 50000, 50000, -50000, -50000
+        for px, py in pts:      # the reference's loop, integer state compared with float coordinates
+            if px < x: x = int(px)
+            if px > x2: x2 = int(px)
+            if py < y: y = int(py)
+            if py > y2: y2 = int(py)
+        assert (r.x, r.y, r.width, r.height) == (x, y, x2 - x, y2 - y)
+        for rot in (1, 2, 3, 4):
+            a = (_Pt * 4)(*[_Pt(float(p), float(q)) for p, q in pts])
+            host.cvarRotSquare(a, rot)
+            exp = np.zeros_like(pts)
+            for i in range(4):
+                exp[(rot - 1 + i) % 4] = pts[i]
+            assert np.array_equal(np.array([[p.x, p.y] for p in a], np.float32), exp)
+        shift = int(rng.integers(0, 4))
+        near = np.roll(pts, -shift, axis=0) + rng.uniform(-10, 10, (4, 2)).astype(np.float32)   # pt2[(i+j)%4] ~ pt1[i]
+        a1 = (_Pt * 4)(*[_Pt(float(p), float(q)) for p, q in pts])
+        a2 = (_Pt * 4)(*[_Pt(float(p), float(q)) for p, q in np.roll(near, 2 * shift, axis=0)])
+        got = host.cvarTrack(a1, a2)
+        p2 = np.array([[p.x, p.y] for p in a2], np.float32)
+        exp_hit, exp_pts = 0, pts
+        for j in range(4):
+            if all(np.hypot(*(pts[i] - p2[(i + j) % 4])) < 20 for i in range(4)):
+                exp_hit, exp_pts = 1, np.array([p2[(i + j) % 4] for i in range(4)])
+                break
+        assert got == exp_hit
+        assert np.array_equal(np.array([[p.x, p.y] for p in a1], np.float32), exp_pts)
+    far = (_Pt * 4)(*[_Pt(1000.0 + i, 1000.0) for i in range(4)])
+    assert host.cvarTrack((_Pt * 4)(*[_Pt(float(i), 0.0) for i in range(4)]), far) == 0
+    # pose through the public helper against the oracle (same tolerance as the GPU parity bar)
+    cam = H.oracle_camera(640, 480)
+    sq = np.array([[200, 150], [330, 160], [320, 290], [190, 280]], np.float32)
+    m_host, m_ref = np.zeros(16), np.zeros(16)
+    host.cvarSquareToMatrix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+    host.cvarSquareToMatrix(P(sq), C.byref(cam), P(m_host), 1.0)
+    H.oracle().orc_square_to_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    H.oracle().orc_square_to_matrix(P(sq), C.byref(cam), 1.0, P(m_ref))
+    assert np.abs(m_host - m_ref).max() <= 1e-4 * max(1.0, np.abs(m_ref).max())
+
+
 @pytest.mark.gpu
 def test_artest_headless_matches_oracle():
     exe = os.path.join(H.PKG, "bin", "artest_headless")
