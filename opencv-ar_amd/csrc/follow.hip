@@ -310,6 +310,9 @@ __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand
         // the border barely turned in SHORT_STEPS steps (an image-sized straight border would only burn tier 2's whole
         // budget before getting there anyway).
         if (!c.is_hole && earlier_start_behind(pl.nbr, pl.ns, pl.plane, c.pos, 0, BACK_STEPS)) return 0;
+        // crops: no border of a crop is longer than tier 2's budget by much (the crop's own frame border is ~4 sides of
+        // <= 260 pixels), so the probe would only repeat what tier 2 does anyway
+        if (CROP) return 1;
         const LeanTrace lt = trace_flat(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
         if (lt.status == TRACE_OVERRUN) return lt.npts <= 2 ? 2 : 1;
         if (lt.status != TRACE_OK || lt.npts < 4) return 0;
