@@ -300,7 +300,8 @@ __device__ bool wave_finish_border(const Workspace& ws, const StartCand c, const
 // Returns true when the start must be queued for the next tier.
 template <bool CROP, int TIER>
 __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand c, int* slab_npts) {
-    const int BUDGET = TIER == 1 ? SHORT_STEPS : ws.mid_steps;
+    static_assert(TIER == 1, "tier 2 is follow_mid_kernel");
+    const int BUDGET = SHORT_STEPS;
     const PlaneRef pl = plane_of<CROP>(ws, c.roi);
     if (c.pos <= 0 || c.pos >= pl.plane) return false;
     if (TIER == 1) {
@@ -318,37 +319,31 @@ __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand
         if (lt.status != TRACE_OK || lt.npts < 4) return 0;
         return 1;
     }
-    if (TIER == 2) {
-        // tier 2 stores the points while it follows (lean loop, private slab): a border that fits needs no second
-        // follow, and its statistics come from the stored points
-        int* slab = ws.slab + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (4 * SLAB_PTS + 4);
-        const LeanTrace lt = trace_flat(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, slab, SLAB_PTS, BUDGET);
-        if (lt.status == TRACE_OVERRUN) return 1;  // budget exhausted: a longer border
-        if (lt.status != TRACE_OK || lt.npts < 4) return false;
-        if (lt.npts <= SLAB_PTS) {
-            *slab_npts = lt.npts;   // finished by the whole wave, one border at a time (follow_kernel)
-            return 3;
-        }
-    }
-    // tier-2 borders with more points than a slab holds: statistics first, then a storing follow into the pool
-    const TraceStats st = trace_border<false, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
+    return 0;
+}
+
+// Tier-2 borders with more corner points than a lane's slab holds (rare: > 1024 corners within the step budget):
+// statistics first, then a storing follow into the pool, approximated by the lane itself.  Returns the route (1 = budget
+// exhausted after all, 0 = done).
+template <bool CROP>
+__device__ int follow_overflow(const Workspace& ws, const StartCand c, const PlaneRef& pl) {
+    const TraceStats st = trace_border<false, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, ws.mid_steps);
     if (st.status == TRACE_OVERRUN) return 1;
-    if (!worth_approximating(st)) return false;
+    if (!worth_approximating(st)) return 0;
     const int need = 2 * st.npts + 2 * (st.npts + 2);
     const long long off = atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
     if (off + need > ws.cap_pool_ints) {
         atomicOr(ws.counters + CNT_ERR, ERR_POOL_OVERFLOW);
-        return false;
+        return 0;
     }
     int* pts = ws.pool + off;
-    trace_border<true, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, pts, st.npts, BUDGET);
+    trace_border<true, false>(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, pts, st.npts, ws.mid_steps);
     approximate_and_emit<CROP>(ws, c, pl, pts, st.npts, st.perimeter, reinterpret_cast<DpSlice*>(pts + 2 * st.npts));
-    return false;
+    return 0;
 }
 
 template <bool CROP, int TIER>
 __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
-    __shared__ DpSlice wstack[4][WAVE_STACK];
     const StartCand* cands = TIER == 1 ? (CROP ? ws.cands_crop : ws.cands_frame) : (CROP ? ws.mid_crop : ws.mid_frame);
     StartCand* longs = TIER == 1 ? (CROP ? ws.mid_crop : ws.mid_frame) : (CROP ? ws.long_crop : ws.long_frame);
     int n = ws.counters[TIER == 1 ? (CROP ? CNT_CROP_CANDS : CNT_FRAME_CANDS) : (CROP ? CNT_MID_C : CNT_MID_F)];
@@ -411,30 +406,6 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
                 route = follow_short<CROP, TIER>(ws, c, &slab_npts);
             }
         }
-        if (TIER == 2) {
-            // borders stored in the lanes' slabs: statistics, approximation and filter by the whole wave, one at a time
-            unsigned long long todo = __ballot(route == 3);
-            if (todo) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // each lane stored its own slab; now every lane reads them
-            while (todo) {
-                const int L = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                StartCand cl;
-                cl.roi = __builtin_amdgcn_readlane(c.roi, L);
-                cl.pos = __builtin_amdgcn_readlane(c.pos, L);
-                cl.is_hole = __builtin_amdgcn_readlane(c.is_hole, L);
-                const int nl = __builtin_amdgcn_readlane(slab_npts, L);
-                const int* slab = ws.slab + ((size_t)blockIdx.x * blockDim.x + uni((int)(threadIdx.x & ~63u)) + L) * (4 * SLAB_PTS + 4);
-                const PlaneRef pl = plane_of<CROP>(ws, cl.roi);
-                if (!wave_finish_border<CROP>(ws, cl, pl, slab, nl, wstack[wave])) {
-                    // deeper recursion than the LDS stack holds: every lane runs the sequential routine on the same data
-                    // (stack in the owner's slab: identical writes), lane 0 publishes
-                    const TraceStats sp = stats_of_points(slab, nl);
-                    if (worth_approximating(sp))
-                        approximate_and_emit<CROP>(ws, cl, pl, slab, nl, sp.perimeter,
-                                                   reinterpret_cast<DpSlice*>(const_cast<int*>(slab) + 2 * SLAB_PTS), lane == 0);
-                }
-            }
-        }
 #pragma unroll
         for (int target = 1; target <= (TIER == 1 ? 2 : 1); target++) {
             StartCand* list = (TIER == 1 && target == 2) ? (CROP ? ws.long_crop : ws.long_frame) : longs;
@@ -449,6 +420,114 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
             if (queue) {
                 const int slot = qbase + __popcll(mask & ((1ull << lane) - 1ull));
                 if (slot < ws.cap_long) list[slot] = c;
+                else atomicOr(ws.counters + CNT_ERR, ERR_CAND_OVERFLOW);
+            }
+        }
+    }
+}
+
+// ---- Tier 2: one lane per surviving border, 64 independent walks per wave, lanes refilled as they finish -------------
+// A walk is a chain of dependent byte loads, so a wave's time is its longest walk; with one batch of 64 starts per wave
+// most lanes would sit idle behind the longest border (a crop holds a ~900-step border next to 100-step ones).  Here a
+// lane whose walk has ended is retired every MID_BLOCK steps -- routed on, or approximated by the whole wave from its
+// slab -- and takes the next start from the list, so the lanes stay busy until the list is empty.
+constexpr int MID_BLOCK = 32;
+
+template <bool CROP>
+__global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
+    __shared__ DpSlice wstack[4][WAVE_STACK];
+    const StartCand* cands = CROP ? ws.mid_crop : ws.mid_frame;
+    StartCand* longs = CROP ? ws.long_crop : ws.long_frame;
+    int n = ws.counters[CROP ? CNT_MID_C : CNT_MID_F];
+    if (n > ws.cap_long) n = ws.cap_long;
+    int* ticket = ws.counters + (CROP ? CNT_TICKET_MC : CNT_TICKET_MF);
+    int* n_long = ws.counters + (CROP ? CNT_LONG_C : CNT_LONG_F);
+    const int lane = threadIdx.x & 63;
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int* slab = ws.slab + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (4 * SLAB_PTS + 4);
+    const int* wave_slabs = ws.slab + ((size_t)blockIdx.x * blockDim.x + uni((int)(threadIdx.x & ~63u))) * (4 * SLAB_PTS + 4);
+    const int budget = ws.mid_steps;
+    bool have = false;   // this lane holds a start whose walk has not been retired
+    bool more = true;    // wave-uniform: the list may still hold starts
+    StartCand c;
+    c.roi = 0; c.pos = 0; c.is_hole = 0;
+    PlaneRef pl = plane_of<CROP>(ws, 0);
+    FlatWalk w;
+    w.status = TRACE_NOT_FIRST;
+    for (;;) {
+        // hand idle lanes the next starts of the list (one ticket fetch for all of them)
+        const unsigned long long idle = __ballot(!have);
+        if (more && idle) {
+            const int cnt = __popcll(idle);
+            int base = 0;
+            if (ticket_lane() == 0) base = atomicAdd(ticket, cnt);
+            base = uni(base);
+            if (base + cnt >= n) more = false;
+            if (!have) {
+                const int idx = base + __popcll(idle & below);
+                if (idx < n) {
+                    c = cands[idx];
+                    pl = plane_of<CROP>(ws, c.roi);
+                    if (c.pos > 0 && c.pos < pl.plane) {
+                        flat_begin(w, pl.nbr, pl.ns, c.pos, c.is_hole);
+                        have = true;
+                    }
+                }
+            }
+        }
+        if (__ballot(have) == 0) break;
+        for (int k = 0; k < MID_BLOCK; k++) {
+            const bool running = have && w.status < 0;
+            if (__ballot(running) == 0) break;
+            if (running) flat_step(w, pl.nbr, pl.ns, pl.plane, c.pos, slab, SLAB_PTS, budget);
+        }
+        // retire the walks that have ended
+        int route = 0, slab_npts = 0;
+        if (have && w.status >= 0) {
+            if (w.status == TRACE_OVERRUN) route = 1;   // budget exhausted: a longer border (tier 3)
+            else if (w.status == TRACE_OK && w.npts >= 4) {
+                if (w.npts <= SLAB_PTS) {
+                    route = 3;   // finished by the whole wave below
+                    slab_npts = w.npts;
+                } else {
+                    route = follow_overflow<CROP>(ws, c, pl);
+                }
+            }
+            have = false;
+        }
+        // borders stored in the lanes' slabs: statistics, approximation and filter by the whole wave, one at a time
+        unsigned long long todo = __ballot(route == 3);
+        if (todo) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // each lane stored its own slab; now every lane reads them
+        while (todo) {
+            const int L = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            StartCand cl;
+            cl.roi = __builtin_amdgcn_readlane(c.roi, L);
+            cl.pos = __builtin_amdgcn_readlane(c.pos, L);
+            cl.is_hole = __builtin_amdgcn_readlane(c.is_hole, L);
+            const int nl = __builtin_amdgcn_readlane(slab_npts, L);
+            const int* sl = wave_slabs + (size_t)L * (4 * SLAB_PTS + 4);
+            const PlaneRef pll = plane_of<CROP>(ws, cl.roi);
+            if (!wave_finish_border<CROP>(ws, cl, pll, sl, nl, wstack[wave])) {
+                // deeper recursion than the LDS stack holds: every lane runs the sequential routine on the same data
+                // (stack in the owner's slab: identical writes), lane 0 publishes
+                const TraceStats sp = stats_of_points(sl, nl);
+                if (worth_approximating(sp))
+                    approximate_and_emit<CROP>(ws, cl, pll, sl, nl, sp.perimeter,
+                                               reinterpret_cast<DpSlice*>(const_cast<int*>(sl) + 2 * SLAB_PTS), lane == 0);
+            }
+        }
+        // budget exhausted: queue for the wave tier
+        const unsigned long long mask = __ballot(route == 1);
+        if (mask) {
+            int qbase = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if (lane == leader) qbase = atomicAdd(n_long, __popcll(mask));
+            qbase = __builtin_amdgcn_readlane(qbase, leader);
+            if (route == 1) {
+                const int slot = qbase + __popcll(mask & below);
+                if (slot < ws.cap_long) longs[slot] = c;
                 else atomicOr(ws.counters + CNT_ERR, ERR_CAND_OVERFLOW);
             }
         }
@@ -754,10 +833,10 @@ void launch_follow_crops(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL((follow_kernel<true, 1>), dim3(1024), dim3(256), 0, stream, ws);
 }
 void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL((follow_kernel<false, 2>), dim3(ws.mid_blocks), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL(follow_mid_kernel<false>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws);
 }
 void launch_follow_mid_crops(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL((follow_kernel<true, 2>), dim3(ws.mid_blocks), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws);
 }
 void launch_follow_long_frames(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_long_kernel<false>, dim3(ws.long_blocks), dim3(256), 0, stream, ws);

@@ -295,58 +295,76 @@ OCVAR_HD LeanTrace trace_lean(const uint8_t* nbr, int ns, int plane, int cpos, i
 // (a lane that ends re-reads its own pixel; a step without a point stores into the scratch slot behind the last
 // point), and the only control flow is the loop itself.  Same results as trace_lean, step for step.
 // out must hold max_pts + 1 points; with max_pts == 0 nothing is stored (out may be null).
+// The walk as a resumable state (tier 2 on the GPU steps 64 independent walks per wave and hands a lane a new start as
+// soon as its walk has ended).  status: -1 while running, then a TraceStatus.
+struct FlatWalk {
+    int x, y, idx, s, prev_s, npts, step, status;
+    unsigned m;
+    int i0, i1;
+};
+
+OCVAR_HD void flat_begin(FlatWalk& w, const uint8_t* nbr, int ns, int cpos, int is_hole) {
+    w.i0 = cpos - is_hole;
+    w.x = w.i0 % ns;
+    w.y = w.i0 / ns;
+    w.idx = w.i0;
+    w.npts = 0;
+    w.step = 0;
+    w.status = -1;
+    w.m = nbr[nbr_addr(w.x, w.y, ns)];
+    w.s = 0;
+    w.prev_s = 0;
+    w.i1 = 0;
+    if (w.m == 0) {   // single-pixel domain (only reachable for outer borders)
+        w.status = TRACE_SINGLE;
+        w.npts = 1;
+        return;
+    }
+    w.s = first_cw(w.m, (is_hole ? 0 : 4) - 1);       // direction of the border's last pixel seen from its first
+    w.i1 = w.i0 + mul_small(step_dy(w.s), ns) + step_dx(w.s);
+    w.prev_s = w.s ^ 4;
+}
+
+// one step of a running walk (w.status < 0)
+OCVAR_HD void flat_step(FlatWalk& w, const uint8_t* nbr, int ns, int plane, int cpos, int* out, int max_pts, int max_steps) {
+    const int from = (w.s + 1) & 7;
+    const int t = __builtin_ctz(((w.m * 0x101u) >> from) & 0xffu);   // zero neighbours passed before the next border pixel
+    const int e = (from + t) & 7;                                     // exit direction
+    const unsigned passed = ((((1u << t) - 1u) * 0x101u) << from) >> 8;   // 8-bit rotate of t ones to position `from`
+    const bool budget = w.step >= max_steps;
+    const bool nf = !budget && (((passed & 0x10u) != 0 && w.idx < cpos) || ((passed & 1u) != 0 && w.idx + 1 < cpos));
+    const int dx = step_dx(e), dy = step_dy(e);
+    const int nidx = w.idx + mul_small(dy, ns) + dx;
+    const bool closes = !budget && !nf && nidx == w.i0 && w.idx == w.i1;
+    const bool oob = !budget && !nf && !closes && (unsigned)nidx >= (unsigned)plane;
+    const bool go = !(budget || nf || closes || oob);
+    const bool emit = e != w.prev_s && (go || closes);   // CHAIN_APPROX_SIMPLE: a point wherever the direction changes
+    const int lx = go ? w.x + dx : w.x, ly = go ? w.y + dy : w.y;
+    const unsigned m4 = nbr[nbr_addr(lx, ly, ns)];
+    if (max_pts > 0) {
+        const int slot = (emit && w.npts < max_pts) ? w.npts : max_pts;
+        out[2 * slot] = w.x;
+        out[2 * slot + 1] = w.y;
+    }
+    w.npts += emit ? 1 : 0;
+    w.status = budget ? (int)TRACE_OVERRUN : nf ? (int)TRACE_NOT_FIRST : closes ? (int)TRACE_OK : (oob || m4 == 0) ? (int)TRACE_OVERRUN : -1;
+    w.step += go ? 1 : 0;
+    w.x = lx;
+    w.y = ly;
+    w.idx = go ? nidx : w.idx;
+    w.prev_s = go ? e : w.prev_s;
+    w.m = m4;
+    w.s = go ? (e ^ 4) : w.s;
+}
+
 OCVAR_HD LeanTrace trace_flat(const uint8_t* nbr, int ns, int plane, int cpos, int is_hole, int* out, int max_pts, int max_steps) {
+    FlatWalk w;
+    flat_begin(w, nbr, ns, cpos, is_hole);
+    while (w.status < 0) flat_step(w, nbr, ns, plane, cpos, out, max_pts, max_steps);
     LeanTrace r;
-    r.status = TRACE_OK;
-    r.npts = 0;
-    r.steps = 0;
-    const int i0 = cpos - is_hole;
-    int x = i0 % ns, y = i0 / ns;
-    unsigned m = nbr[nbr_addr(x, y, ns)];
-    if (m == 0) {
-        r.status = TRACE_SINGLE;
-        r.npts = 1;
-        return r;
-    }
-    int s = first_cw(m, (is_hole ? 0 : 4) - 1);
-    const int i1 = i0 + mul_small(step_dy(s), ns) + step_dx(s);
-    int idx = i0;
-    int prev_s = s ^ 4;
-    int npts = 0, step = 0;
-    int status = -1;   // running
-    while (status < 0) {
-        const int from = (s + 1) & 7;
-        const int t = __builtin_ctz(((m * 0x101u) >> from) & 0xffu);   // zero neighbours passed before the next border pixel
-        const int e = (from + t) & 7;                                   // exit direction
-        const unsigned passed = ((((1u << t) - 1u) * 0x101u) << from) >> 8;   // 8-bit rotate of t ones to position `from`
-        const bool budget = step >= max_steps;
-        const bool nf = !budget && (((passed & 0x10u) != 0 && idx < cpos) || ((passed & 1u) != 0 && idx + 1 < cpos));
-        const int dx = step_dx(e), dy = step_dy(e);
-        const int nidx = idx + mul_small(dy, ns) + dx;
-        const bool closes = !budget && !nf && nidx == i0 && idx == i1;
-        const bool oob = !budget && !nf && !closes && (unsigned)nidx >= (unsigned)plane;
-        const bool go = !(budget || nf || closes || oob);
-        const bool emit = e != prev_s && (go || closes);   // CHAIN_APPROX_SIMPLE: a point wherever the direction changes
-        const int lx = go ? x + dx : x, ly = go ? y + dy : y;
-        const unsigned m4 = nbr[nbr_addr(lx, ly, ns)];
-        if (max_pts > 0) {
-            const int slot = (emit && npts < max_pts) ? npts : max_pts;
-            out[2 * slot] = x;
-            out[2 * slot + 1] = y;
-        }
-        npts += emit ? 1 : 0;
-        status = budget ? (int)TRACE_OVERRUN : nf ? (int)TRACE_NOT_FIRST : closes ? (int)TRACE_OK : (oob || m4 == 0) ? (int)TRACE_OVERRUN : -1;
-        step += go ? 1 : 0;
-        x = lx;
-        y = ly;
-        idx = go ? nidx : idx;
-        prev_s = go ? e : prev_s;
-        m = m4;
-        s = go ? (e ^ 4) : s;
-    }
-    r.status = status;
-    r.npts = npts;
-    r.steps = step;
+    r.status = w.status;
+    r.npts = w.npts;
+    r.steps = w.step;
     return r;
 }
 
