@@ -197,11 +197,11 @@ def main():
         kernels = [
             ("binarise_frames_kernel", 0, 5.0 * WH * Bs),          # 3 B BGR read + 1 B grey + 1 B mask per pixel
             ("follow_kernel<frames,1>", 1, 1.0 * WH * Bs / 16),     # touches masks near borders only; bound: latency
-            ("follow_kernel<frames,2>", 2, 1.0 * WH * Bs / 16),
+            ("follow_mid_kernel<frames>", 2, 1.0 * WH * Bs / 16),
             ("follow_long_kernel<frames>", 3, 1.0 * WH * Bs / 16),
             ("binarise_crops_kernel", 5, 2.0 * crop_pixels * Bs),   # grey crop read + mask write
             ("follow_kernel<crops,1>", 6, 1.0 * crop_pixels * Bs / 16),
-            ("follow_kernel<crops,2>", 7, 1.0 * crop_pixels * Bs / 16),
+            ("follow_mid_kernel<crops>", 7, 1.0 * crop_pixels * Bs / 16),
             ("follow_long_kernel<crops>", 8, 1.0 * crop_pixels * Bs / 16),
         ]
         dom = max(kernels, key=lambda k: stage_ms[k[1]])
