@@ -15,6 +15,7 @@
 //   pyrDown  [1 4 6 4 1]^2, (v+128)>>8, BORDER_REFLECT_101        pyrUp  [1 6 1]/[4 4], (v+32)>>6, borders -1->1, n->n-1
 //   Gaussian [8 28 56 72 56 28 8]^2, (v+32768)>>16, BORDER_REPLICATE    threshold  src - mean > -8
 #include "kernels.h"
+#include <cstdlib>
 
 namespace ocvar {
 

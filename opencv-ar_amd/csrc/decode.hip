@@ -11,7 +11,9 @@
 
 namespace ocvar {
 
-__global__ __launch_bounds__(64) void decode_kernel(Workspace ws) {
+// (register budget of 4 waves per SIMD = 128 VGPRs: the binarise kernels of other contexts fill the SIMDs with 7 waves of
+// 70 VGPRs, and a wave that needs 246 registers waits until most of them have drained)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void decode_kernel(Workspace ws) {
     const int f = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ws.n_squares[f] || i >= MAXQ) return;
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(64) void decode_kernel(Workspace ws) {
 
 constexpr int MAXC = 2048;  // candidates per frame the tail keeps in LDS
 
-__global__ __launch_bounds__(64) void finalise_kernel(Workspace ws) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8), amdgpu_num_vgpr(128))) void finalise_kernel(Workspace ws) {
     __shared__ int s_mid[MAXC];
     __shared__ int s_tid[MAXC];
     __shared__ unsigned char s_score[MAXC];
