@@ -262,6 +262,29 @@ def test_stream_tracker_three_steps_two_streams(oa):
             ref_prev[s], _, _ = H.oracle_registration(frames[s], tpls, cam, prev=ref_prev[s])
 
 
+def test_results_to_device_block_equals_collect(oa):
+    """ocvar_hip_results_to_device (the block a rank hands to the RCCL gather) holds exactly what ocvar_hip_collect
+    returns, and sharding.unpack decodes it."""
+    import torch
+    from opencv_ar_amd import sharding as S
+    cfg = H.synth_config(2)
+    n = 5
+    det, tpls, cam = make_detector(oa, cfg, ["2x2-01"], n)
+    frames = np.stack([H.synth_frame(cfg, f, ["2x2-01"])[0] for f in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    block = torch.zeros(S.block_bytes(n), dtype=torch.uint8, device="cuda")
+    det.enqueue_device(d.data_ptr(), cfg.width, cfg.height, n)
+    det.results_to_device(block.data_ptr(), block.data_ptr() + n * S.MAX_MARKERS * S.MARKER_BYTES)
+    markers, counts = det.collect()
+    torch.cuda.synchronize()
+    res = S.unpack([block], n, oa.MARKER_DTYPE)
+    assert sorted(res) == list(range(n))
+    for f in range(n):
+        c, m = res[f]
+        assert c == counts[f] and c >= 1
+        assert m.tobytes() == markers[f, :c].tobytes()
+
+
 def test_round_trip_properties_full_size(oa):
     """Size-independent properties at the headline size: determinism across batch positions, and every decoded
     4x4 marker's quad lies on a planted marker (corner within 12 px of the truth: the decoded quad is the inner border)."""
