@@ -1,9 +1,10 @@
 // follow.hip -- border following + polygon approximation + quad filter, and the per-frame ordering that turns
 // the surviving quads into the reference's square sequence and into crop work for the second pass (gfx950).
 //
-// follow_kernel replaces the contour half of cvarFindSquares (/root/reference/src/opencvar.cpp:183-214) for
-// every ROI of a pass at once: one lane per plausible border start (trace_core.h), waves pull 64 starts at a
-// time from a ticket counter so that a long border only holds up its own wave.
+// follow_kernel (tier 1, a router), follow_mid_kernel (tier 2) and follow_long_kernel (tier 3) replace the contour half
+// of cvarFindSquares (/root/reference/src/opencvar.cpp:183-214) for every ROI of a pass at once: every plausible border
+// start (trace_core.h) is a work item pulled from a ticket counter; tier 1 decides which starts are worth following,
+// tier 2 follows 64 borders per wave (one lane each), tier 3 one image-sized border per wave.
 // order_and_crops_kernel replaces cvarGetAllSquares (564-590), the tracking loop (635-668) and the crop
 // rectangle set-up of the candidate loop (676-693).
 #include "kernels.h"
@@ -293,11 +294,9 @@ __device__ bool wave_finish_border(const Workspace& ws, const StartCand c, const
     return true;
 }
 
-// Tiers 1 and 2, one lane per start, mask bytes read from global memory (one memory latency per step, 64 borders
-// per wave in flight).  Tier 1 sees every plausible start with a small step budget: most drop out or close within a
-// few steps (noise, staircase false starts).  Tier 2 re-follows the survivors of tier 1 -- now densely packed, a few
-// hundred steps each -- with a larger budget.  What outlives tier 2 (image-sized borders) goes to tier 3.
-// Returns true when the start must be queued for the next tier.
+// Tier 1, one lane per start, mask bytes read from global memory (one memory latency per step, 64 starts per wave in
+// flight).  It sees every plausible start, and most of them drop out within a few steps (noise, staircase false
+// starts).  Returns the route: 0 = dead, 1 = tier 2, 2 = straight to tier 3.
 template <bool CROP, int TIER>
 __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand c, int* slab_npts) {
     static_assert(TIER == 1, "tier 2 is follow_mid_kernel");
