@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on an MI355X: many synthetic scenes (sizes incl. odd ones, clean/textured backgrounds,
+marker sizes, rotations, perspective jitter, occlusion, 1..3 templates, post-processing noise/blur/contrast) through
+the HIP path and the oracle, compared with the same bars as tests/test_gpu_parity.py (grey plane, binary image, quads,
+decoded candidates bit-exact; markers exact / pose 1e-4).  Not part of the default test run (minutes of CPU oracle time).
+
+    python tools/fuzz_parity.py [n_scenes] [seed]
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import helpers as H
+import opencv_ar_amd as oa
+import test_gpu_parity as T
+
+n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+sizes = [(640, 480), (641, 479), (800, 600), (1001, 701), (1280, 720), (333, 517), (1920, 1080), (96, 64), (250, 250)]
+t0 = time.time()
+frames_checked = markers_seen = cands_seen = 0
+for s in range(n_scenes):
+    w, h = sizes[int(rng.integers(len(sizes)))]
+    names = [H.TEMPLATE_ORDER[i] for i in sorted(rng.choice(3, size=int(rng.integers(1, 4)), replace=False))]
+    side_min = int(rng.integers(40, 120))
+    cell = max(side_min + 60, 140)
+    gx, gy = max(1, min(6, w // (cell + 40))), max(1, min(4, h // (cell + 40)))
+    cfg = H.synth_config(3, width=w, height=h, grid_x=gx, grid_y=gy, side_min=side_min, side_max=side_min + int(rng.integers(0, 60)),
+                         rot_mode=int(rng.integers(0, 3)), corner_jitter_pct=int(rng.integers(0, 12)),
+                         occlude_pct=int(rng.choice([0, 0, 20, 50])), textured=int(rng.integers(0, 2)))
+    nb = int(rng.integers(1, 4))
+    frames = []
+    for f in range(nb):
+        img = H.synth_frame(cfg, int(rng.integers(0, 1 << 20)), names)[0].astype(np.int32)
+        mode = int(rng.integers(0, 5))
+        if mode == 1:      # sensor noise, per channel (exercises BGR2GRAY with unequal channels)
+            img += rng.integers(-9, 10, img.shape)
+        elif mode == 2:    # low contrast + offset
+            img = img * int(rng.integers(30, 90)) // 100 + int(rng.integers(0, 80))
+        elif mode == 3:    # colour cast
+            img = img * np.array([rng.integers(60, 101), rng.integers(60, 101), rng.integers(60, 101)]) // 100
+        elif mode == 4:    # 3-tap blur along x
+            img = (img + np.roll(img, 1, 1) + np.roll(img, -1, 1)) // 3
+        frames.append(np.clip(img, 0, 255).astype(np.uint8))
+    frames = np.ascontiguousarray(np.stack(frames))
+    det, tpls, cam = T.make_detector(oa, cfg, names, nb)
+    markers, counts = det.detect_host(frames.copy())
+    for f in range(nb):
+        ref_m, n_c = T.check_frame(det, f, frames[f], tpls, cam, markers, counts)
+        frames_checked += 1; markers_seen += len(ref_m); cands_seen += n_c
+    del det
+    if (s + 1) % 10 == 0:
+        print(f"scene {s + 1}/{n_scenes}: {frames_checked} frames equal so far ({cands_seen} decoded candidates, {markers_seen} markers), {time.time() - t0:.0f} s", flush=True)
+print(f"fuzz_parity: {frames_checked} frames, {cands_seen} candidates, {markers_seen} markers: all equal")
