@@ -44,10 +44,23 @@ for s in range(n_scenes):
         frames.append(np.clip(img, 0, 255).astype(np.uint8))
     frames = np.ascontiguousarray(np.stack(frames))
     det, tpls, cam = T.make_detector(oa, cfg, names, nb)
-    markers, counts = det.detect_host(frames.copy())
-    for f in range(nb):
-        ref_m, n_c = T.check_frame(det, f, frames[f], tpls, cam, markers, counts)
-        frames_checked += 1; markers_seen += len(ref_m); cands_seen += n_c
+    if s % 4 == 3:     # stateful: every lane is a video stream, the scene drifts a few pixels per step (opencvar.cpp:635-668)
+        from opencv_ar_amd.tracking import StreamTracker
+        tracker = StreamTracker(det, nb)
+        prev = [None] * nb
+        cur = frames
+        for step in range(3):
+            markers, counts = tracker.step(cur.copy())
+            for f in range(nb):
+                ref_m, n_c = T.check_frame(det, f, cur[f], tpls, cam, markers, counts, prev=prev[f])
+                prev[f] = ref_m
+                frames_checked += 1; markers_seen += len(ref_m); cands_seen += n_c
+            cur = np.ascontiguousarray(np.roll(cur, (int(rng.integers(-6, 7)), int(rng.integers(-6, 7))), axis=(1, 2)))
+    else:
+        markers, counts = det.detect_host(frames.copy())
+        for f in range(nb):
+            ref_m, n_c = T.check_frame(det, f, frames[f], tpls, cam, markers, counts)
+            frames_checked += 1; markers_seen += len(ref_m); cands_seen += n_c
     del det
     if (s + 1) % 10 == 0:
         print(f"scene {s + 1}/{n_scenes}: {frames_checked} frames equal so far ({cands_seen} decoded candidates, {markers_seen} markers), {time.time() - t0:.0f} s", flush=True)
