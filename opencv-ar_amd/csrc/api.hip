@@ -217,7 +217,7 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
         static const long long min_units = std::getenv("OCVAR_MIN_UNITS") ? std::atoll(std::getenv("OCVAR_MIN_UNITS")) : 65536;
         while (chunks > 1 && (long long)w.frame_strips * (chunks / 2) * n_frames >= min_units) chunks /= 2;
         int rows = (w.sh + chunks - 1) / chunks;
-        rows = (rows + 1) & ~1;
+        rows = (rows + 7) & ~7;   // whole mask tiles (8 rows) per work unit: binarise.hip writes the mask plane tile by tile
         w.frame_chunk_rows = rows;
         w.frame_chunks = (w.sh + rows - 1) / rows;
     }

@@ -78,7 +78,7 @@ struct MarchOut {
 // One work unit: strip `strip` of an (sw x sh) ROI, output rows [Y0, Y1).
 template <bool BGR>
 __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int sh, int strip, int Y0, int Y1, const MarchOut& o,
-                           unsigned* stage) {
+                           unsigned* stage, unsigned* rowbuf /* LDS, 8 rows x 64 lanes */) {
     const int lane = threadIdx.x & 63;
     const int XS = strip * SV - 4 * HL;
     const int c0 = XS + 4 * lane;
@@ -103,12 +103,34 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     // per-lane byte offsets (unsigned: the row bases are wave-uniform, so loads/stores can use the SGPR-base + 32-bit VGPR offset form)
     const unsigned src_off = fast ? (unsigned)(c0 * (BGR ? 3 : 1)) : 0u;
     const unsigned out_off = out_lane ? (unsigned)c0 : 0u;
-    const unsigned nbr_off = out_lane ? nbr_col_off(c0) : 0u;
     const unsigned right_bits = lane == 63 - HR ? 0x202020u : 0x202060u;   // the last output lane's x+2 bit (row above) is not computed
     unsigned colmask = 0;  // which of the lane's 4 columns lie inside cvFindContours' zeroed frame
     for (int j = 0; j < 4; j++) colmask |= (c0 + j >= 1 && c0 + j <= sw - 2) ? (1u << j) : 0u;
     unsigned pxmask = 0;   // bit 8j: the lane's pixel j is an output pixel of this strip
     for (int j = 0; j < 4; j++) pxmask |= (out_lane && c0 + j < sw) ? (1u << (8 * j)) : 0u;
+
+    // Mask rows are collected in LDS, 8 rows at a time, and written as whole 16x8-pixel tiles (128 contiguous bytes, 32
+    // per lane) -- a row at a time would be 16-byte pieces of 15 different cache lines per wave, and on this hardware a
+    // store issued in every iteration makes the loop-top wait for the prefetched source row wait for that store too
+    // (vmcnt counts loads and stores in order).  Y0 is a multiple of 8 (api.hip / MARCH_CROP_ROWS), so a group of 8 rows
+    // belongs to one work unit; padding rows/columns of the plane (rows up to sh rounded to 8, columns up to ns) may
+    // receive stale values, nothing reads them.
+    const int tile_x = strip * (SV / 16) + (lane >> 2);          // lanes 0..59: tile of this strip, 4 lanes per tile
+    const bool flush_lane = lane < 4 * (SV / 16) && tile_x * 16 < o.ns;
+    const unsigned flush_src = (unsigned)(2 * (lane & 3)) * 64u + (unsigned)(HL + 4 * (lane >> 2));   // dword index in rowbuf: row 2p, first lane of the tile
+    const unsigned flush_dst = ((unsigned)tile_x << 7) + (unsigned)(2 * (lane & 3)) * 16u;           // byte offset inside a tile row group
+    auto flush_rows = [&](int yr_last) {   // yr_last: last row written; its group is complete or the unit ends
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (flush_lane) {
+            const uint2* s0 = reinterpret_cast<const uint2*>(rowbuf + flush_src);
+            const uint2 a0 = s0[0], a1 = s0[1];       // row 2p: 16 bytes
+            const uint2 b0 = s0[32], b1 = s0[33];     // row 2p+1 (one row = 64 dwords = 32 uint2)
+            uint8_t* dst = o.nbr + wave_uniform64(((long long)((yr_last >> 3) * (o.ns >> 4))) << 7) + flush_dst;
+            reinterpret_cast<uint4*>(dst)[0] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            reinterpret_cast<uint4*>(dst)[1] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    };
 
     // Border starts are staged per wave in LDS and appended to the global list with ONE atomic per flush: a
     // single list counter only sustains ~90 atomics/us chip-wide, which one atomic per image row would exceed.
@@ -303,7 +325,8 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                     const unsigned centre = (Ms >> 1) & 0x01010101u, west = Ms & 0x01010101u;
                     const unsigned nbr4 = ((Ms >> 2) & 0x01010101u) | (__builtin_amdgcn_perm(As, As, 0x00010203u) << 1) | (west << 4) |
                                           Bs;   // E | NE N NW | W | SW S SE
-                    if (out_lane) *reinterpret_cast<unsigned*>(o.nbr + wave_uniform64(nbr_row_off(yr, o.ns)) + nbr_off) = nbr4;
+                    rowbuf[(yr & 7) * 64 + lane] = nbr4;
+                    if ((yr & 7) == 7 || yr == Y1 - 1) flush_rows(yr);
                     // Plausible border starts (sparse): necessary local conditions for being the raster-first pixel of a region.
                     // Outer: foreground pixel whose W, NW, N, NE are background -- and not (E foreground and the pixel above E's
                     // east neighbour foreground: that one belongs to the same 8-connected component and comes earlier).
@@ -337,6 +360,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
 
 __global__ __launch_bounds__(256) void binarise_frames_kernel(Workspace ws, const uint8_t* bgr, int row_stride, size_t frame_stride) {
     __shared__ unsigned stage[4][MARCH_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned rowbuf[4][8 * 64];
     const int unit = blockIdx.x * 4 + wave_uniform((int)(threadIdx.x >> 6));
     const int per_frame = ws.frame_strips * ws.frame_chunks;
     if (unit >= per_frame * ws.n_frames) return;
@@ -354,7 +378,7 @@ __global__ __launch_bounds__(256) void binarise_frames_kernel(Workspace ws, cons
     o.n_cands = ws.counters + CNT_FRAME_CANDS;
     o.cap_cands = ws.cap_frame_cands;
     o.err = ws.counters + CNT_ERR;
-    march_unit<true>(bgr + (size_t)f * frame_stride, row_stride, ws.sw, ws.sh, strip, Y0, Y1, o, stage[wave_uniform((int)(threadIdx.x >> 6))]);
+    march_unit<true>(bgr + (size_t)f * frame_stride, row_stride, ws.sw, ws.sh, strip, Y0, Y1, o, stage[wave_uniform((int)(threadIdx.x >> 6))], rowbuf[wave_uniform((int)(threadIdx.x >> 6))]);
 }
 
 // Odd width / height: the last column / row lies outside the even working size (opencvar.cpp:158) but is still
@@ -388,6 +412,7 @@ __global__ __launch_bounds__(256) void grey_writeback_kernel(Workspace ws, uint8
 
 __global__ __launch_bounds__(256) void binarise_crops_kernel(Workspace ws) {
     __shared__ unsigned stage[4][MARCH_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned rowbuf[4][8 * 64];
     int n_units = ws.counters[CNT_CROP_TILES];
     if (n_units > ws.cap_crop_tiles) n_units = ws.cap_crop_tiles;
     const int wave = wave_uniform((int)(threadIdx.x >> 6));
@@ -406,7 +431,7 @@ __global__ __launch_bounds__(256) void binarise_crops_kernel(Workspace ws) {
         o.n_cands = ws.counters + CNT_CROP_CANDS;
         o.cap_cands = ws.cap_crop_cands;
         o.err = ws.counters + CNT_ERR;
-        march_unit<false>(src, ws.W, r.sw, r.sh, td.x0, td.y0, Y1, o, stage[wave]);
+        march_unit<false>(src, ws.W, r.sw, r.sh, td.x0, td.y0, Y1, o, stage[wave], rowbuf[wave]);
     }
 }
 
