@@ -416,7 +416,16 @@ __global__ __launch_bounds__(256) void binarise_crops_kernel(Workspace ws) {
     int n_units = ws.counters[CNT_CROP_TILES];
     if (n_units > ws.cap_crop_tiles) n_units = ws.cap_crop_tiles;
     const int wave = wave_uniform((int)(threadIdx.x >> 6));
-    for (int u = blockIdx.x * 4 + wave; u < n_units; u += gridDim.x * 4) {
+    // crop units differ in size (rows, and the follow-up of their start lists): waves pull them from a ticket counter.
+    // (The ticket test uses an opaque copy of the lane id: see follow.hip::ticket_lane for the compiler hazard.)
+    int* ticket = ws.counters + CNT_TICKET_BC;
+    for (;;) {
+        int lane_id = (int)(threadIdx.x & 63);
+        asm volatile("" : "+v"(lane_id));
+        int u = 0;
+        if (lane_id == 0) u = atomicAdd(ticket, 1);
+        u = wave_uniform(u);
+        if (u >= n_units) break;
         const TileDesc td = ws.tiles_crop[u];
         const Roi r = ws.rois_crop[td.roi];
         const uint8_t* src = ws.gray + (size_t)r.frame * ws.W * ws.H + (size_t)r.y0 * ws.W + r.x0;
