@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import helpers as H
 import opencv_ar_amd as oa
-B, CAL = 64, 1 << 28
+B, CAL = int(os.environ.get("TRAFFIC_B", "64")), 1 << 28
 cfg = H.synth_config(3)
 frames = np.stack([H.synth_frame(cfg, i)[0] for i in range(16)] * (B // 16))
 tpls = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, n + ".png") for n in H.TEMPLATE_ORDER])
