@@ -383,12 +383,18 @@ extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int
         else if (e == hipErrorHostMemoryAlreadyRegistered) pinned = true;
         (void)hipGetLastError();
     }
-    if (!pinned) {
-        HIP_TRY(c, hipMemcpy(c->d_frames, h_bgr, bytes, hipMemcpyHostToDevice));
-        rc = ocvar_hip_detect_device(c, c->d_frames, width, height, row_stride, frame_stride, n_frames, grey_in_place, prev,
-                                     prev_counts, markers, counts, max_per_frame);
-        if (rc) return rc;
-        if (grey_in_place) HIP_TRY(c, hipMemcpy(h_bgr, c->d_frames, bytes, hipMemcpyDeviceToHost));
+    if (!pinned) {   // one frame, or a buffer that cannot be page-locked: synchronous copies, sub-batch by sub-batch
+        const int sub = c->ws.max_batch;
+        for (int k = 0; k * sub < n_frames; k++) {
+            const int cnt = (k + 1) * sub <= n_frames ? sub : n_frames - k * sub;
+            const size_t off = (size_t)k * sub * frame_stride, len = (size_t)(cnt - 1) * frame_stride + frame_bytes;
+            HIP_TRY(c, hipMemcpy(c->d_frames + off, h_bgr + off, len, hipMemcpyHostToDevice));
+            rc = ocvar_hip_detect_device(c, c->d_frames + off, width, height, row_stride, frame_stride, cnt, grey_in_place,
+                                         prev ? prev + (size_t)k * sub * MAXM : nullptr, prev_counts ? prev_counts + k * sub : nullptr,
+                                         markers ? markers + (size_t)k * sub * max_per_frame : nullptr, counts + k * sub, max_per_frame);
+            if (rc) return rc;
+            if (grey_in_place) HIP_TRY(c, hipMemcpy(h_bgr + off, c->d_frames + off, len, hipMemcpyDeviceToHost));
+        }
         return OCVAR_OK;
     }
 
