@@ -85,7 +85,9 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     w.cap_crop_rois = (int)(B * MAXQ);
     w.cap_crop_tiles = (int)std::min<size_t>(B * 4096, (size_t)1 << 30);
     w.cap_crop_quads = (int)(B * MAXQ * 4);
-    w.cap_pool_ints = (long long)B * (1 << 18) + (1 << 20);   // only tier-2 borders with more corner points than a lane slab holds land here
+    // only tier-2 borders with more corner points than a lane slab holds land here; the fixed part lets a small context take
+    // a pathological frame (full-frame noise: thousands of long ragged borders)
+    w.cap_pool_ints = (long long)B * (1 << 18) + (1 << 24);
     w.cap_crop_pixels = (long long)(2 * B * (size_t)(max_width + 16) * (max_height + 8));
     int rc;
     if ((rc = dev_alloc(c, &w.gray, B * WH))) return rc;
@@ -96,7 +98,7 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     if ((rc = dev_alloc(c, &w.pool, (size_t)w.cap_pool_ints))) return rc;
     if ((rc = dev_alloc(c, &w.slab, (size_t)MID_BLOCKS_MAX * 256 * (4 * SLAB_PTS + 4)))) return rc;
     if ((rc = dev_alloc(c, &w.slab3, (size_t)LONG_BLOCKS_MAX * 4 * (4 * SLAB3_PTS + 4)))) return rc;
-    w.cap_long = (int)std::min<size_t>(B * 4096, (size_t)1 << 28);
+    w.cap_long = (int)std::min<size_t>(std::max<size_t>(B * 4096, (size_t)1 << 18), (size_t)1 << 28);   // survivors of tier 1 / tier 2: a noise frame has ~10^4
     if ((rc = dev_alloc(c, &w.mid_frame, (size_t)w.cap_long))) return rc;
     if ((rc = dev_alloc(c, &w.mid_crop, (size_t)w.cap_long))) return rc;
     if ((rc = dev_alloc(c, &w.long_frame, (size_t)w.cap_long))) return rc;

@@ -738,8 +738,31 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
         if (lt.status == TRACE_OVERRUN) {
             if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TRACE_OVERRUN);
         } else if (lt.status == TRACE_OK && lt.npts >= 4) {
-            if (lt.npts > SLAB3_PTS) {   // more contour points than the slab holds: report, never truncate silently
-                if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_POOL_OVERFLOW);
+            if (lt.npts > SLAB3_PTS) {
+                // more corner points than the wave's slab holds (a percolating noise cluster, a sawtooth the size of the
+                // frame): the count is known now, so take points + stack from the pool and follow once more, storing all.
+                // Out of pool: report, never truncate silently.
+                const long long need = 4ll * lt.npts + 8;
+                unsigned long long off = 0;
+                if (lane == 0) off = atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
+                off = uni(off);
+                if ((long long)off + need > ws.cap_pool_ints) {
+                    if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_POOL_OVERFLOW);
+                } else {
+                    int* big = ws.pool + off;
+                    t.tx0 = t.ty0 = -(1 << 28);
+                    const LeanTrace lt2 = trace_lean_tiled(t, c.pos, c.is_hole, big, lt.npts, 4 * uni(pl.plane) + 16);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    if (lt2.status == TRACE_OK && lt2.npts == lt.npts) {
+                        if (!wave_finish_border<CROP>(ws, c, pl, big, lt2.npts, wstack[wave])) {
+                            const TraceStats sp = stats_of_points(big, lt2.npts);
+                            if (worth_approximating(sp))
+                                approximate_and_emit<CROP>(ws, c, pl, big, lt2.npts, sp.perimeter, reinterpret_cast<DpSlice*>(big + 2 * lt2.npts), lane == 0);
+                        }
+                    } else if (lane == 0) {
+                        atomicOr(ws.counters + CNT_ERR, ERR_TRACE_OVERRUN);
+                    }
+                }
             } else {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // points stored by other lanes of this wave (same CU: L1 is coherent)
                 if (!wave_finish_border<CROP>(ws, c, pl, slab, lt.npts, wstack[wave])) {

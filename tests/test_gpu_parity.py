@@ -262,6 +262,21 @@ def test_stream_tracker_three_steps_two_streams(oa):
             ref_prev[s], _, _ = H.oracle_registration(frames[s], tpls, cam, prev=ref_prev[s])
 
 
+def test_pathological_noise_frames_are_handled_exactly(oa):
+    """Full-frame blocky noise: tens of thousands of plausible starts, thousands of tier-1 survivors and percolating
+    clusters whose borders have more corner points than a wave slab holds (tier 3 then follows again into the pool).
+    The reference takes any frame; so does this path, with the same result."""
+    rng = np.random.default_rng(12)
+    w, h, cell = 1920, 1080, 4
+    cfg = H.synth_config(3, width=w, height=h)
+    det, tpls, cam = make_detector(oa, cfg, None, 1)
+    frame = np.ascontiguousarray(np.kron(rng.integers(0, 2, (h // cell, w // cell, 1), np.uint8) * 255, np.ones((cell, cell, 3), np.uint8)))
+    markers, counts = det.detect_host(frame[None].copy())
+    pool_ints = det.counters()[5]
+    check_frame(det, 0, frame, tpls, cam, markers, counts)
+    assert pool_ints > 0    # the point pool was used: some border exceeded a slab
+
+
 def test_results_to_device_block_equals_collect(oa):
     """ocvar_hip_results_to_device (the block a rank hands to the RCCL gather) holds exactly what ocvar_hip_collect
     returns, and sharding.unpack decodes it."""
