@@ -96,8 +96,12 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     if ((rc = dev_alloc(c, &w.cands_frame, (size_t)w.cap_frame_cands))) return rc;
     if ((rc = dev_alloc(c, &w.cands_crop, (size_t)w.cap_crop_cands))) return rc;
     if ((rc = dev_alloc(c, &w.pool, (size_t)w.cap_pool_ints))) return rc;
-    if ((rc = dev_alloc(c, &w.slab, (size_t)MID_BLOCKS_MAX * 256 * (4 * SLAB_PTS + 4)))) return rc;
-    if ((rc = dev_alloc(c, &w.slab3, (size_t)LONG_BLOCKS_MAX * 4 * (4 * SLAB3_PTS + 4)))) return rc;
+    // follower grids (and their slabs) scale with the batch: a one-frame context (the reference's per-frame call) does not
+    // need -- or pay for -- the 512 + 1024 workgroups that keep a 2048-frame batch busy
+    w.max_mid_blocks = (int)std::min<size_t>(MID_BLOCKS_MAX, std::max<size_t>(32, B * 8));
+    w.max_long_blocks = (int)std::min<size_t>(LONG_BLOCKS_MAX, std::max<size_t>(32, B * 8));
+    if ((rc = dev_alloc(c, &w.slab, (size_t)w.max_mid_blocks * 256 * SLAB_STRIDE))) return rc;
+    if ((rc = dev_alloc(c, &w.slab3, (size_t)w.max_long_blocks * 4 * SLAB3_STRIDE))) return rc;
     w.cap_long = (int)std::min<size_t>(std::max<size_t>(B * 4096, (size_t)1 << 18), (size_t)1 << 28);   // survivors of tier 1 / tier 2: a noise frame has ~10^4
     if ((rc = dev_alloc(c, &w.mid_frame, (size_t)w.cap_long))) return rc;
     if ((rc = dev_alloc(c, &w.mid_crop, (size_t)w.cap_long))) return rc;
@@ -205,10 +209,11 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     w.ns = (w.sw + 15) & ~15;
     w.n_frames = n_frames;
     w.mid_steps = std::getenv("OCVAR_MID_STEPS") ? std::atoi(std::getenv("OCVAR_MID_STEPS")) : MID_STEPS;
-    w.mid_blocks = std::getenv("OCVAR_MID_BLOCKS") ? std::atoi(std::getenv("OCVAR_MID_BLOCKS")) : MID_BLOCKS_MAX;
-    if (w.mid_blocks < 1 || w.mid_blocks > MID_BLOCKS_MAX) w.mid_blocks = MID_BLOCKS_MAX;
-    w.long_blocks = std::getenv("OCVAR_LONG_BLOCKS") ? std::atoi(std::getenv("OCVAR_LONG_BLOCKS")) : LONG_BLOCKS_MAX;
-    if (w.long_blocks < 1 || w.long_blocks > LONG_BLOCKS_MAX) w.long_blocks = LONG_BLOCKS_MAX;
+    w.mid_blocks = std::getenv("OCVAR_MID_BLOCKS") ? std::atoi(std::getenv("OCVAR_MID_BLOCKS")) : w.max_mid_blocks;
+    if (w.mid_blocks < 1 || w.mid_blocks > w.max_mid_blocks) w.mid_blocks = w.max_mid_blocks;
+    w.long_blocks = std::getenv("OCVAR_LONG_BLOCKS") ? std::atoi(std::getenv("OCVAR_LONG_BLOCKS")) : w.max_long_blocks;
+    if (w.long_blocks < 1 || w.long_blocks > w.max_long_blocks) w.long_blocks = w.max_long_blocks;
+    w.dbg = std::getenv("OCVAR_DBG") ? std::atoi(std::getenv("OCVAR_DBG")) : 0;
     w.frame_strips = (w.sw + MARCH_STRIP - 1) / MARCH_STRIP;
     {   // rows per binarise work unit: even, chunks of equal size.  Every chunk re-reads ~12 halo rows, so chunks are as
         // tall as the batch allows while the launch still has >= 64K waves (env OCVAR_MIN_UNITS); never < ~128 rows.  (Measured: choosing the
@@ -290,7 +295,7 @@ static int wait_impl(OcvarHip* c) {
     const int e = c->h_counters[CNT_ERR];
     if (e) {
         char buf[160];
-        std::snprintf(buf, sizeof buf, "device work list overflow / trace overrun, flags 0x%x (1 starts, 2 point pool, 4 quads, 8 overrun, 16 crops, 32 tiles)", e);
+        std::snprintf(buf, sizeof buf, "device work list overflow / trace overrun, flags 0x%x (1 starts, 2 point pool, 4 quads, 8 overrun, 16 crops, 32 tiles, 64 ticket runaway, 128 markers)", e);
         c->err = buf;
         return OCVAR_E_CAPACITY;
     }

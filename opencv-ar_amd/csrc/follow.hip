@@ -96,70 +96,85 @@ __device__ __forceinline__ void emit_quad(const Workspace& ws, const StartCand c
 }
 
 // ---- wave-cooperative statistics + polygon approximation ------------------------------------------------------
-// One border at a time, all 64 lanes on its stored points: the scans of cvApproxPoly (farthest point from the
-// start, farthest point from a chord) are strided over the lanes with coalesced loads and finished by a wave
-// max-reduction; the slice stack and the handful of output vertices are wave-uniform.  Results are bit-identical
-// to trace_core.h::approx_poly_dp / stats_of_points ("first maximum wins" = largest value, then smallest index;
-// the perimeter is a sum of float32 values small enough that every partial sum is exact in double, so the
-// summation order does not matter).
+// One border at a time, all 64 lanes on its stored points (packed x | y << 16).  The points are first staged in LDS
+// (one coalesced pass that also yields the bounding box), so every later access of the approximation -- the scans of
+// cvApproxPoly (farthest point from the start, farthest point from a chord) strided over the lanes, and the wave-uniform
+// reads of slice end points on the dependent chain -- costs an LDS access instead of a global-memory round trip, and the
+// wave reductions run on DPP (six VALU steps) instead of twelve ds_bpermute exchanges.  Results are bit-identical to
+// trace_core.h::approx_poly_dp / stats_of_points ("first maximum wins" = largest value, then smallest index; the
+// perimeter is a sum of float32 values small enough that every partial sum is exact in double, so the summation order
+// does not matter).  The slice stack never holds more than DP_MAX_OUT + 1 entries (trace_core.h).
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ unsigned dpp_self(unsigned v) {   // lanes the pattern does not reach keep their own value
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWS, 0xf, false);
+}
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ unsigned dpp_zero(unsigned v) {   // lanes the pattern does not reach receive 0
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false);
+}
+// Reduction ladder of a 64-lane wave: xor 1, xor 2 (quad_perm), half-row mirror, row mirror, then lane 15 of rows 0/2 to
+// rows 1/3 and lane 31 to rows 2/3; lane 63 ends up with the result.
+#define OCVAR_WAVE_LADDER(STEP) \
+    STEP(0xB1, 0xf) STEP(0x4E, 0xf) STEP(0x141, 0xf) STEP(0x140, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define STEP(C, R) { const unsigned o = dpp_self<C, R>(v); v = o > v ? o : v; }
+    OCVAR_WAVE_LADDER(STEP)
+#undef STEP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        v = o > v ? o : v;
-    }
-    return uni(v);
+#define STEP(C, R) { const unsigned long long o = ((unsigned long long)dpp_self<C, R>((unsigned)(v >> 32)) << 32) | dpp_self<C, R>((unsigned)v); v = o > v ? o : v; }
+    OCVAR_WAVE_LADDER(STEP)
+#undef STEP
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63) << 32) |
+           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
 }
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
-    return uni(v);
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+// both halves of a packed point at once (v_pk_min_u16 / v_pk_max_u16)
+__device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2v, a), __builtin_bit_cast(us2v, b))); }
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2v, a), __builtin_bit_cast(us2v, b))); }
+__device__ __forceinline__ unsigned wave_pk_min(unsigned v) {
+#define STEP(C, R) v = pk_min(v, dpp_self<C, R>(v));
+    OCVAR_WAVE_LADDER(STEP)
+#undef STEP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
-    return uni(v);
+__device__ __forceinline__ unsigned wave_pk_max(unsigned v) {
+#define STEP(C, R) v = pk_max(v, dpp_self<C, R>(v));
+    OCVAR_WAVE_LADDER(STEP)
+#undef STEP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const long long b = __double_as_longlong(v);
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)b, off), hi = (unsigned)__shfl_xor((int)(unsigned)((unsigned long long)b >> 32), off);
-        v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-    }
-    return uni(v);
+#define STEP(C, R) { const unsigned long long b = (unsigned long long)__double_as_longlong(v); \
+                     v += __longlong_as_double((long long)(((unsigned long long)dpp_zero<C, R>((unsigned)(b >> 32)) << 32) | dpp_zero<C, R>((unsigned)b))); }
+    OCVAR_WAVE_LADDER(STEP)
+#undef STEP
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63) << 32) |
+                                            (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63)));
 }
 
-__device__ TraceStats wave_stats_of_points(const int* pts, int n) {
-    const int lane = threadIdx.x & 63;
-    int minx = 0x7fffffff, miny = 0x7fffffff, maxx = -0x7fffffff, maxy = -0x7fffffff;
-    double per = 0.0;
-    for (int i = lane; i < n; i += 64) {
-        const int x = pts[2 * i], y = pts[2 * i + 1];
-        const int p = i == 0 ? n - 1 : i - 1;
-        const int px = pts[2 * p], py = pts[2 * p + 1];
-        minx = x < minx ? x : minx; maxx = x > maxx ? x : maxx;
-        miny = y < miny ? y : miny; maxy = y > maxy ? y : maxy;
-        if (n > 1) {
-            const float dx = (float)x - (float)px, dy = (float)y - (float)py;
-            per += (double)sqrt_rn(dx * dx + dy * dy);
-        }
-    }
-    TraceStats st;
-    st.status = TRACE_OK;
-    st.npts = n;
-    st.steps = 0;
-    st.minx = wave_min_i32(minx); st.maxx = wave_max_i32(maxx);
-    st.miny = wave_min_i32(miny); st.maxy = wave_max_i32(maxy);
-    st.perimeter = wave_sum_f64(per);
-    return st;
-}
+__device__ __forceinline__ int px_of(unsigned p) { return (int)(p & 0xffffu); }
+__device__ __forceinline__ int py_of(unsigned p) { return (int)(p >> 16); }
 
-constexpr int WAVE_STACK = 96;   // slices of the cooperative approximation's LDS stack
+constexpr int LDS_PTS = SLAB_PTS;   // points of one border a wave can stage in LDS
+constexpr int DP_DST = 2 * (DP_MAX_OUT + 1);
 
-// returns the vertex count (DP_MAX_OUT+1 = "more than 4 after clean-up"), or -1 if the LDS stack would overflow
-__device__ int wave_approx_poly_dp(const int* src, int count, double parameter, int* dst, DpSlice* stack /* LDS, WAVE_STACK */) {
+// Per-wave LDS scratch of the finishing code.
+struct WaveScratch {
+    unsigned pts[LDS_PTS];
+    DpSlice stack[DP_STACK];
+    int dst[DP_DST];
+};
+
+// cvApproxPoly on packed points (src: LDS or global memory; the address space is resolved at the inlined call site).
+// K32: keys of the maximum searches are (value << 11 | ~index), valid when count <= 1024 and the squared diagonal of the
+// bounding box is < 2^21 (every squared distance and every cross product of the border is then < 2^21).
+// Returns the vertex count (DP_MAX_OUT+1 = "more than 4 after clean-up"); the vertices are left in dst (LDS).
+template <bool K32>
+__device__ __forceinline__ int wave_approx_dp(const unsigned* src, int count, double parameter, int* dst, DpSlice* stack) {
     const int lane = threadIdx.x & 63;
     float eps = (float)parameter;
     eps *= eps;
@@ -170,20 +185,39 @@ __device__ int wave_approx_poly_dp(const int* src, int count, double parameter, 
     int pos = 0;
     for (int it = 0; it < 3; it++) {
         pos = (pos + right.start) % count;
-        sx = uni(src[2 * pos]);
-        sy = uni(src[2 * pos + 1]);
-        unsigned long long best = 0;
-        for (int j = 1 + lane; j < count; j += 64) {
-            int q = pos + j;
-            q = q >= count ? q - count : q;
-            const int dx = src[2 * q] - sx, dy = src[2 * q + 1] - sy;
-            const unsigned dist = (unsigned)(dx * dx + dy * dy);
-            const unsigned long long key = dist ? ((unsigned long long)dist << 32) | (unsigned)~(unsigned)j : 0ull;
-            best = key > best ? key : best;
+        const unsigned sp = uni(src[pos]);
+        sx = px_of(sp);
+        sy = py_of(sp);
+        int max_dist = 0;
+        if (K32) {
+            unsigned best = 0;
+            for (int j = 1 + lane; j < count; j += 64) {
+                int q = pos + j;
+                q = q >= count ? q - count : q;
+                const unsigned p = src[q];
+                const int dx = px_of(p) - sx, dy = py_of(p) - sy;
+                const unsigned dist = (unsigned)(dx * dx + dy * dy);
+                const unsigned key = dist ? (dist << 11) | (~(unsigned)j & 0x7ffu) : 0u;
+                best = key > best ? key : best;
+            }
+            best = wave_max_u32(best);
+            max_dist = (int)(best >> 11);
+            if (best) right.start = (int)(~best & 0x7ffu);
+        } else {
+            unsigned long long best = 0;
+            for (int j = 1 + lane; j < count; j += 64) {
+                int q = pos + j;
+                q = q >= count ? q - count : q;
+                const unsigned p = src[q];
+                const int dx = px_of(p) - sx, dy = py_of(p) - sy;
+                const unsigned dist = (unsigned)(dx * dx + dy * dy);
+                const unsigned long long key = dist ? ((unsigned long long)dist << 32) | (unsigned)~(unsigned)j : 0ull;
+                best = key > best ? key : best;
+            }
+            best = wave_max_u64(best);
+            max_dist = (int)(best >> 32);
+            if (best) right.start = (int)~(unsigned)best;
         }
-        best = wave_max_u64(best);
-        const int max_dist = (int)(best >> 32);
-        if (best) right.start = (int)~(unsigned)best;
         le_eps = (float)max_dist <= eps;
     }
     if (le_eps) {
@@ -210,22 +244,41 @@ __device__ int wave_approx_poly_dp(const int* src, int count, double parameter, 
         slice.end = uni(stack[top].end);
         const int e = slice.end >= count ? slice.end - count : slice.end;
         const int b = slice.start >= count ? slice.start - count : slice.start;
-        const int ex = uni(src[2 * e]), ey = uni(src[2 * e + 1]);
-        sx = uni(src[2 * b]);
-        sy = uni(src[2 * b + 1]);
+        const unsigned ep = uni(src[e]), bp = uni(src[b]);
+        const int ex = px_of(ep), ey = py_of(ep);
+        sx = px_of(bp);
+        sy = py_of(bp);
         if (slice.end > slice.start + 1) {
             const int dx = ex - sx, dy = ey - sy;
-            unsigned long long best = 0;
-            for (int i = slice.start + 1 + lane; i < slice.end; i += 64) {
-                const int q = i >= count ? i - count : i;
-                int d = (src[2 * q + 1] - sy) * dx - (src[2 * q] - sx) * dy;
-                d = d < 0 ? -d : d;
-                const unsigned long long key = d ? ((unsigned long long)(unsigned)d << 32) | (unsigned)~(unsigned)i : 0ull;
-                best = key > best ? key : best;
+            int max_dist = 0;
+            if (K32) {
+                unsigned best = 0;
+                for (int i = slice.start + 1 + lane; i < slice.end; i += 64) {
+                    const int q = i >= count ? i - count : i;
+                    const unsigned p = src[q];
+                    int d = (py_of(p) - sy) * dx - (px_of(p) - sx) * dy;
+                    d = d < 0 ? -d : d;
+                    const unsigned key = d ? ((unsigned)d << 11) | (~(unsigned)i & 0x7ffu) : 0u;
+                    best = key > best ? key : best;
+                }
+                best = wave_max_u32(best);
+                max_dist = (int)(best >> 11);
+                // (i < 2 * count <= 2048: the index fits its 11 bits)
+                if (best) right.start = (int)(~best & 0x7ffu);
+            } else {
+                unsigned long long best = 0;
+                for (int i = slice.start + 1 + lane; i < slice.end; i += 64) {
+                    const int q = i >= count ? i - count : i;
+                    const unsigned p = src[q];
+                    int d = (py_of(p) - sy) * dx - (px_of(p) - sx) * dy;
+                    d = d < 0 ? -d : d;
+                    const unsigned long long key = d ? ((unsigned long long)(unsigned)d << 32) | (unsigned)~(unsigned)i : 0ull;
+                    best = key > best ? key : best;
+                }
+                best = wave_max_u64(best);
+                max_dist = (int)(best >> 32);
+                if (best) right.start = (int)~(unsigned)best;
             }
-            best = wave_max_u64(best);
-            const int max_dist = (int)(best >> 32);
-            if (best) right.start = (int)~(unsigned)best;
             le_eps = (double)max_dist * max_dist <= (double)eps * ((double)dx * dx + (double)dy * dy);
         } else {
             le_eps = true;
@@ -238,7 +291,7 @@ __device__ int wave_approx_poly_dp(const int* src, int count, double parameter, 
         } else {
             right.end = slice.end;
             slice.end = right.start;
-            if (top + 2 > WAVE_STACK) return -1;
+            if (new_count + top + 2 > DP_MAX_OUT) return DP_MAX_OUT + 1;   // every waiting slice ends in >= 1 vertex
             if (lane == 0) {
                 stack[top] = right;
                 stack[top + 1] = slice;
@@ -246,7 +299,8 @@ __device__ int wave_approx_poly_dp(const int* src, int count, double parameter, 
             top += 2;
         }
     }
-    // clean-up of nearly collinear vertices on the closed ring (wave-uniform, <= 8 vertices)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    // clean-up of nearly collinear vertices on the closed ring (wave-uniform, <= 8 vertices, all lanes write the same values)
     const int n = new_count;
     int r = n - 1;
     sx = dst[2 * r];
@@ -278,19 +332,45 @@ __device__ int wave_approx_poly_dp(const int* src, int count, double parameter, 
         px = ex;
         py = ey;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     return new_count;
 }
 
-// statistics + approximation + filter + publication of one stored border by the whole wave; false if the LDS stack
-// is too small for this border (the caller then falls back to the one-lane routine)
-template <bool CROP>
-__device__ bool wave_finish_border(const Workspace& ws, const StartCand c, const PlaneRef& pl, const int* pts, int npts, DpSlice* lds_stack) {
-    const TraceStats sp = wave_stats_of_points(pts, npts);
-    if (!worth_approximating(sp)) return true;
-    int dst[2 * (DP_MAX_OUT + 1)];
-    const int m = wave_approx_poly_dp(pts, npts, sp.perimeter * 0.02, dst, lds_stack);
-    if (m < 0) return false;
-    if (m == 4 && quad_filter(dst, pl.img_w, pl.img_h) && (threadIdx.x & 63) == 0) emit_quad<CROP>(ws, c, dst);
+// Statistics + approximation + filter + publication of one stored border (npts packed points at gsrc in global memory)
+// by the whole wave.  STAGE: the points fit the wave's LDS scratch (npts <= LDS_PTS).  Returns whether a quad was published.
+template <bool CROP, bool STAGE>
+__device__ __forceinline__ bool wave_finish_packed(const Workspace& ws, const StartCand c, const PlaneRef& pl, const unsigned* gsrc, int npts,
+                                                   WaveScratch* sc) {
+    const int lane = threadIdx.x & 63;
+    if (npts < 4) return false;
+    unsigned lo = 0xffffffffu, hi = 0u;
+    for (int i = lane; i < npts; i += 64) {
+        const unsigned p = gsrc[i];
+        if (STAGE) sc->pts[i] = p;
+        lo = pk_min(lo, p);
+        hi = pk_max(hi, p);
+    }
+    lo = wave_pk_min(lo);
+    hi = wave_pk_max(hi);
+    const int bw = px_of(hi) - px_of(lo), bh = py_of(hi) - py_of(lo);
+    if (!((long long)bw * bh > 500)) return false;   // worth_approximating: the quad filter needs |area| > 500
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const unsigned* src = STAGE ? sc->pts : gsrc;
+    double per = 0.0;
+    for (int i = lane; i < npts; i += 64) {
+        const unsigned p = src[i], q = src[i == 0 ? npts - 1 : i - 1];
+        const float dx = (float)px_of(p) - (float)px_of(q), dy = (float)py_of(p) - (float)py_of(q);
+        per += (double)sqrt_rn(dx * dx + dy * dy);
+    }
+    per = wave_sum_f64(per);
+    const bool k32 = npts <= 1024 && (long long)bw * bw + (long long)bh * bh < (1ll << 21);
+    const int m = k32 ? wave_approx_dp<true>(src, npts, per * 0.02, sc->dst, sc->stack) : wave_approx_dp<false>(src, npts, per * 0.02, sc->dst, sc->stack);
+    if (m != 4) return false;
+    int q[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) q[k] = uni(sc->dst[k]);
+    if (!quad_filter(q, pl.img_w, pl.img_h)) return false;
+    if (lane == 0) emit_quad<CROP>(ws, c, q);
     return true;
 }
 
@@ -431,10 +511,17 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
 // lane whose walk has ended is retired every MID_BLOCK steps -- routed on, or approximated by the whole wave from its
 // slab -- and takes the next start from the list, so the lanes stay busy until the list is empty.
 constexpr int MID_BLOCK = 32;
+// A walk's corner points are not stored to its slab step by step -- 64 lanes x one dword in 64 different cache lines per
+// step made the stores, not the dependent mask loads, the bulk of this kernel's time (1.7 of 2.8 ms per 2048 frames) --
+// but parked in LDS (row of POINT_ROW dwords per lane: up to MID_BLOCK points + the dummy slot of steps without a point;
+// the odd row length spreads the lanes over the banks) and appended to the slabs after every block of steps, two lanes'
+// rows per store instruction, each a contiguous run of up to 128 bytes.
+constexpr int POINT_ROW = MID_BLOCK + 1;
 
 template <bool CROP>
 __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
-    __shared__ DpSlice wstack[4][WAVE_STACK];
+    __shared__ WaveScratch scratch[4];
+    __shared__ unsigned parked[4][64 * POINT_ROW];
     const StartCand* cands = CROP ? ws.mid_crop : ws.mid_frame;
     StartCand* longs = CROP ? ws.long_crop : ws.long_frame;
     int n = ws.counters[CROP ? CNT_MID_C : CNT_MID_F];
@@ -444,8 +531,10 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
     const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6));
     const unsigned long long below = (1ull << lane) - 1ull;
-    int* slab = ws.slab + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (4 * SLAB_PTS + 4);
-    const int* wave_slabs = ws.slab + ((size_t)blockIdx.x * blockDim.x + uni((int)(threadIdx.x & ~63u))) * (4 * SLAB_PTS + 4);
+    unsigned* wave_slabs = reinterpret_cast<unsigned*>(ws.slab) + ((size_t)blockIdx.x * blockDim.x + uni((int)(threadIdx.x & ~63u))) * SLAB_STRIDE;
+    unsigned* my_row = parked[wave] + lane * POINT_ROW;
+    const unsigned* wave_rows = parked[wave];
+    int flushed = 0;     // points of this lane's walk already in its slab
     const int budget = ws.mid_steps;
     bool have = false;   // this lane holds a start whose walk has not been retired
     bool more = true;    // wave-uniform: the list may still hold starts
@@ -454,7 +543,13 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
     PlaneRef pl = plane_of<CROP>(ws, 0);
     FlatWalk w;
     w.status = TRACE_NOT_FIRST;
+    // every round hands out at least one start or retires at least one walk after <= budget / MID_BLOCK rounds of stepping
+    long long guard = ((long long)n + 64) * (budget / MID_BLOCK + 4) + 64;
     for (;;) {
+        if (--guard < 0) {
+            if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TICKET_RUNAWAY);
+            break;
+        }
         // hand idle lanes the next starts of the list (one ticket fetch for all of them)
         const unsigned long long idle = __ballot(!have);
         if (more && idle) {
@@ -471,6 +566,7 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
                     if (c.pos > 0 && c.pos < pl.plane) {
                         flat_begin(w, pl.nbr, pl.ns, c.pos, c.is_hole);
                         have = true;
+                        flushed = 0;
                     }
                 }
             }
@@ -479,7 +575,30 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
         for (int k = 0; k < MID_BLOCK; k++) {
             const bool running = have && w.status < 0;
             if (__ballot(running) == 0) break;
-            if (running) flat_step(w, pl.nbr, pl.ns, pl.plane, c.pos, slab, SLAB_PTS, budget);
+            if (running)
+                flat_step_t(w, pl.nbr, pl.ns, pl.plane, c.pos, budget, [&](bool emit, int x, int y) {
+                    my_row[(emit && w.npts < SLAB_PTS) ? w.npts - flushed : MID_BLOCK] = (unsigned)x | ((unsigned)y << 16);
+                });
+        }
+        {   // append the parked points to the slabs: lanes 0..31 carry one walk's row, lanes 32..63 the next one's
+            const int stored = w.npts < SLAB_PTS ? w.npts : SLAB_PTS;
+            const int pend = have ? stored - flushed : 0;
+            unsigned long long fm = __ballot(pend > 0);
+            if (fm) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            while (fm) {
+                const int La = __ffsll((long long)fm) - 1;
+                fm &= fm - 1;
+                const int Lb = fm ? __ffsll((long long)fm) - 1 : La;
+                const int cb = fm ? __builtin_amdgcn_readlane(pend, Lb) : 0;
+                fm &= fm - 1;   // (0 & -1 stays 0)
+                const int ca = __builtin_amdgcn_readlane(pend, La);
+                const int oa = __builtin_amdgcn_readlane(flushed, La), ob = __builtin_amdgcn_readlane(flushed, Lb);
+                const bool hi = lane >= 32;
+                const int k = lane & 31;
+                const int L = hi ? Lb : La, cnt = hi ? cb : ca, off = hi ? ob : oa;
+                if (k < cnt) wave_slabs[(size_t)L * SLAB_STRIDE + off + k] = wave_rows[L * POINT_ROW + k];
+            }
+            flushed += pend;
         }
         // retire the walks that have ended
         int route = 0, slab_npts = 0;
@@ -506,16 +625,9 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
             cl.pos = __builtin_amdgcn_readlane(c.pos, L);
             cl.is_hole = __builtin_amdgcn_readlane(c.is_hole, L);
             const int nl = __builtin_amdgcn_readlane(slab_npts, L);
-            const int* sl = wave_slabs + (size_t)L * (4 * SLAB_PTS + 4);
+            const unsigned* sl = wave_slabs + (size_t)L * SLAB_STRIDE;
             const PlaneRef pll = plane_of<CROP>(ws, cl.roi);
-            if (!wave_finish_border<CROP>(ws, cl, pll, sl, nl, wstack[wave])) {
-                // deeper recursion than the LDS stack holds: every lane runs the sequential routine on the same data
-                // (stack in the owner's slab: identical writes), lane 0 publishes
-                const TraceStats sp = stats_of_points(sl, nl);
-                if (worth_approximating(sp))
-                    approximate_and_emit<CROP>(ws, cl, pll, sl, nl, sp.perimeter,
-                                               reinterpret_cast<DpSlice*>(const_cast<int*>(sl) + 2 * SLAB_PTS), lane == 0);
-            }
+            if (!(ws.dbg & 1)) wave_finish_packed<CROP, true>(ws, cl, pll, sl, nl, &scratch[wave]);
         }
         // budget exhausted: queue for the wave tier
         const unsigned long long mask = __ballot(route == 1);
@@ -570,8 +682,8 @@ __device__ __forceinline__ unsigned tile_get(TileCache& t, int x, int y) {
 
 // Lean follower on the tile cache.  All 64 lanes walk the same border and the walker's state (position, direction,
 // mask, counters) is wave-uniform -- kept in SGPRs, stepped by the scalar ALU, branches scalar.  Corner points are
-// parked in a lane of (hx,hy) (lane = point index mod 64) and written 64 at a time, one coalesced 512-byte store,
-// up to max_pts (the count keeps running beyond it); statistics are recomputed from the points afterwards.
+// parked packed (x | y << 16) in a lane of hp (lane = point index mod 64) and written 64 at a time, one coalesced
+// 256-byte store, up to max_pts (the count keeps running beyond it); statistics are recomputed from the points afterwards.
 __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* out, int max_pts, int max_steps) {
     const int lane = threadIdx.x & 63;
     LeanTrace r;
@@ -593,8 +705,8 @@ __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* 
     int prev_s = s ^ 4;
     int straight = 0;  // consecutive straight steps through identical masks (a long run is likely once this is 2)
     int step = 0;
-    int hx = 0, hy = 0;
-    int2* out2 = reinterpret_cast<int2*>(out);
+    unsigned hp = 0;
+    unsigned* out1 = reinterpret_cast<unsigned*>(out);
     for (;; step++) {
         if (step >= max_steps) {
             r.status = TRACE_OVERRUN;
@@ -612,9 +724,8 @@ __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* 
         if (e != prev_s) {
             if (r.npts < max_pts) {
                 const int slot = r.npts & 63;
-                hx = lane == slot ? x : hx;   // v_cndmask: no EXEC change
-                hy = lane == slot ? y : hy;
-                if (slot == 63) out2[r.npts - 63 + lane] = make_int2(hx, hy);
+                hp = lane == slot ? ((unsigned)x | ((unsigned)y << 16)) : hp;   // v_cndmask: no EXEC change
+                if (slot == 63) out1[r.npts - 63 + lane] = hp;
             }
             r.npts++;
             prev_s = e;
@@ -699,7 +810,7 @@ __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* 
     if (r.status == TRACE_OK) {   // the points still parked in lanes
         const int stored = r.npts < max_pts ? r.npts : max_pts;
         const int rem = stored & 63;
-        if (lane < rem) out2[stored - rem + lane] = make_int2(hx, hy);
+        if (lane < rem) out1[stored - rem + lane] = hp;
     }
     r.steps = step;
     return r;
@@ -708,16 +819,22 @@ __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* 
 template <bool CROP>
 __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
     __shared__ __attribute__((aligned(16))) uint8_t tiles[4][TILE * TILE];
-    __shared__ DpSlice wstack[4][WAVE_STACK];
+    __shared__ WaveScratch scratch[4];
     const StartCand* longs = CROP ? ws.long_crop : ws.long_frame;
     int n = ws.counters[CROP ? CNT_LONG_C : CNT_LONG_F];
     if (n > ws.cap_long) n = ws.cap_long;
     int* ticket = ws.counters + (CROP ? CNT_TICKET_LC : CNT_TICKET_LF);
     const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6));
-    // this wave's point + stack space in global memory
-    int* slab = ws.slab3 + ((size_t)blockIdx.x * 4 + wave) * (4 * SLAB3_PTS + 4);
-    for (;;) {
+    // this wave's point space in global memory
+    int* slab = ws.slab3 + ((size_t)blockIdx.x * 4 + wave) * SLAB3_STRIDE;
+    // a ticket is issued at most n + (waves of the grid) times: more iterations than that means the loop's control flow is
+    // broken (see ticket_lane()); report instead of spinning
+    for (int guard = n + 2;; guard--) {
+        if (guard < 0) {
+            if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TICKET_RUNAWAY);
+            break;
+        }
         int idx = 0;
         if (ticket_lane() == 0) idx = atomicAdd(ticket, 1);
         idx = uni(idx);
@@ -740,9 +857,9 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
         } else if (lt.status == TRACE_OK && lt.npts >= 4) {
             if (lt.npts > SLAB3_PTS) {
                 // more corner points than the wave's slab holds (a percolating noise cluster, a sawtooth the size of the
-                // frame): the count is known now, so take points + stack from the pool and follow once more, storing all.
-                // Out of pool: report, never truncate silently.
-                const long long need = 4ll * lt.npts + 8;
+                // frame): the count is known now, so take the points' space from the pool and follow once more, storing
+                // all.  Out of pool: report, never truncate silently.
+                const long long need = (long long)lt.npts + 64;
                 unsigned long long off = 0;
                 if (lane == 0) off = atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)need);
                 off = uni(off);
@@ -754,24 +871,15 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
                     const LeanTrace lt2 = trace_lean_tiled(t, c.pos, c.is_hole, big, lt.npts, 4 * uni(pl.plane) + 16);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                     if (lt2.status == TRACE_OK && lt2.npts == lt.npts) {
-                        if (!wave_finish_border<CROP>(ws, c, pl, big, lt2.npts, wstack[wave])) {
-                            const TraceStats sp = stats_of_points(big, lt2.npts);
-                            if (worth_approximating(sp))
-                                approximate_and_emit<CROP>(ws, c, pl, big, lt2.npts, sp.perimeter, reinterpret_cast<DpSlice*>(big + 2 * lt2.npts), lane == 0);
-                        }
+                        wave_finish_packed<CROP, false>(ws, c, pl, reinterpret_cast<const unsigned*>(big), lt2.npts, &scratch[wave]);
                     } else if (lane == 0) {
                         atomicOr(ws.counters + CNT_ERR, ERR_TRACE_OVERRUN);
                     }
                 }
             } else {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // points stored by other lanes of this wave (same CU: L1 is coherent)
-                if (!wave_finish_border<CROP>(ws, c, pl, slab, lt.npts, wstack[wave])) {
-                    // deeper recursion than the LDS stack holds: every lane runs the sequential routine on the same data
-                    // (stack behind the points in the slab: identical writes), lane 0 publishes
-                    const TraceStats sp = stats_of_points(slab, lt.npts);
-                    if (worth_approximating(sp))
-                        approximate_and_emit<CROP>(ws, c, pl, slab, lt.npts, sp.perimeter, reinterpret_cast<DpSlice*>(slab + 2 * SLAB3_PTS), lane == 0);
-                }
+                if (lt.npts <= LDS_PTS) wave_finish_packed<CROP, true>(ws, c, pl, reinterpret_cast<const unsigned*>(slab), lt.npts, &scratch[wave]);
+                else wave_finish_packed<CROP, false>(ws, c, pl, reinterpret_cast<const unsigned*>(slab), lt.npts, &scratch[wave]);
             }
         }
     }

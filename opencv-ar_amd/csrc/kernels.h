@@ -19,15 +19,19 @@ constexpr int BACK_STEPS = 32;
 constexpr int PRE_STEPS = 8;               // steps every plausible start gets before it may queue for tier 1's full budget
 constexpr int SHORT_STEPS = 96;            // step budget of follower tier 1 (every plausible start, one lane each)
 constexpr int MID_STEPS = 1536;            // step budget of tier 2 (borders that outlived tier 1, one lane each); the rest: tier 3, one wave each
-constexpr int SLAB_PTS = 1024;             // points a tier-2 lane can keep in its private slab (no second follow needed below that)
+constexpr int SLAB_PTS = 1024;             // points (packed x | y << 16) a tier-2 lane can keep in its private slab (no second follow needed below that)
+constexpr int SLAB_STRIDE = SLAB_PTS + 4;  // dwords per tier-2 lane slab: the points + the scratch slot of flat_step
 constexpr int MID_BLOCKS_MAX = 512;        // tier-2 grid limit (x256 threads, one slab each)
 constexpr int SLAB3_PTS = 8192;            // points a tier-3 wave can keep in its slab
+constexpr int SLAB3_STRIDE = SLAB3_PTS + 64;   // dwords per tier-3 wave slab
 constexpr int LONG_BLOCKS_MAX = 1024;      // tier-3 grid limit (x4 waves, one slab each)
 constexpr int TILE = 64;                   // side of the LDS tile the wave-per-border follower walks in             // backward look of an outer start before it follows its border
 
 // error bits accumulated in Workspace::err[0]
 enum { ERR_CAND_OVERFLOW = 1, ERR_POOL_OVERFLOW = 2, ERR_QUAD_OVERFLOW = 4, ERR_TRACE_OVERRUN = 8, ERR_CROP_OVERFLOW = 16,
-       ERR_TILE_OVERFLOW = 32 };
+       ERR_TILE_OVERFLOW = 32,
+       ERR_TICKET_RUNAWAY = 64,     // a work-queue loop ran more iterations than its list can account for (control flow broken)
+       ERR_MARKER_OVERFLOW = 128 }; // more than OCVAR_MAX_MARKERS markers in one frame
 
 struct TileDesc { int roi, x0, y0; };   // binarise work unit of the crop pass: x0 = strip index, y0 = first row
 
@@ -52,6 +56,8 @@ struct Workspace {
     // per batch geometry
     int W, H, sw, sh, ns, n_frames, n_templates;   // ns: row stride of a neighbour-mask plane = sw rounded up to 4
     int mid_steps, mid_blocks, long_blocks;  // tuning (env OCVAR_MID_STEPS / OCVAR_MID_BLOCKS / OCVAR_LONG_BLOCKS): tier-2 step budget and grid, tier-3 grid
+    int dbg;  // TEMP diagnostics
+    int max_mid_blocks, max_long_blocks;     // slabs allocated at create (scaled with max_batch)
     int frame_strips, frame_chunks, frame_chunk_rows;  // binarise work decomposition of a frame
     // device buffers
     uint8_t* gray;          // [B][H][W]
@@ -65,8 +71,8 @@ struct Workspace {
     StartCand* long_crop;
     int cap_long;
     int* pool;              // points + DP stacks
-    int* slab;              // [MID_BLOCKS_MAX*256][4*SLAB_PTS+4] private point + stack space of the tier-2 lanes
-    int* slab3;             // [LONG_BLOCKS_MAX*4][4*SLAB3_PTS+4] point + stack space of the tier-3 waves
+    int* slab;              // [max_mid_blocks*256][SLAB_STRIDE] private point space of the tier-2 lanes
+    int* slab3;             // [max_long_blocks*4][SLAB3_STRIDE] point space of the tier-3 waves
     QuadRec* quads_frame;   // [B][MAXQ] unordered
     int* n_quads_frame;     // [B]
     float* squares;         // [B][MAXQ][8] ordered, after tracking

@@ -325,8 +325,11 @@ OCVAR_HD void flat_begin(FlatWalk& w, const uint8_t* nbr, int ns, int cpos, int 
     w.prev_s = w.s ^ 4;
 }
 
-// one step of a running walk (w.status < 0)
-OCVAR_HD void flat_step(FlatWalk& w, const uint8_t* nbr, int ns, int plane, int cpos, int* out, int max_pts, int max_steps) {
+// one step of a running walk (w.status < 0).  store(emit, x, y) is called once per step between the request for
+// the next mask and the state update: emit = the pixel being left is a corner point, x/y its position (the caller decides
+// where a point -- or the dummy of a step without one -- goes; see flat_step and follow.hip's tier 2).
+template <class Store>
+OCVAR_HD void flat_step_t(FlatWalk& w, const uint8_t* nbr, int ns, int plane, int cpos, int max_steps, Store&& store) {
     const int from = (w.s + 1) & 7;
     const int t = __builtin_ctz(((w.m * 0x101u) >> from) & 0xffu);   // zero neighbours passed before the next border pixel
     const int e = (from + t) & 7;                                     // exit direction
@@ -341,11 +344,7 @@ OCVAR_HD void flat_step(FlatWalk& w, const uint8_t* nbr, int ns, int plane, int 
     const bool emit = e != w.prev_s && (go || closes);   // CHAIN_APPROX_SIMPLE: a point wherever the direction changes
     const int lx = go ? w.x + dx : w.x, ly = go ? w.y + dy : w.y;
     const unsigned m4 = nbr[nbr_addr(lx, ly, ns)];
-    if (max_pts > 0) {
-        const int slot = (emit && w.npts < max_pts) ? w.npts : max_pts;
-        out[2 * slot] = w.x;
-        out[2 * slot + 1] = w.y;
-    }
+    store(emit, w.x, w.y);
     w.npts += emit ? 1 : 0;
     w.status = budget ? (int)TRACE_OVERRUN : nf ? (int)TRACE_NOT_FIRST : closes ? (int)TRACE_OK : (oob || m4 == 0) ? (int)TRACE_OVERRUN : -1;
     w.step += go ? 1 : 0;
@@ -355,6 +354,17 @@ OCVAR_HD void flat_step(FlatWalk& w, const uint8_t* nbr, int ns, int plane, int 
     w.prev_s = go ? e : w.prev_s;
     w.m = m4;
     w.s = go ? (e ^ 4) : w.s;
+}
+
+// points as x,y int pairs in out (max_pts + 1 pairs: a step without a point stores into the scratch slot behind the last)
+OCVAR_HD void flat_step(FlatWalk& w, const uint8_t* nbr, int ns, int plane, int cpos, int* out, int max_pts, int max_steps) {
+    flat_step_t(w, nbr, ns, plane, cpos, max_steps, [&](bool emit, int x, int y) {
+        if (max_pts > 0) {
+            const int slot = (emit && w.npts < max_pts) ? w.npts : max_pts;
+            out[2 * slot] = x;
+            out[2 * slot + 1] = y;
+        }
+    });
 }
 
 OCVAR_HD LeanTrace trace_flat(const uint8_t* nbr, int ns, int plane, int cpos, int is_hole, int* out, int max_pts, int max_steps) {
@@ -440,10 +450,13 @@ OCVAR_HD bool earlier_start_behind(const uint8_t* nbr, int sw, int plane, int cp
 struct DpSlice { int start, end; };
 
 // cvApproxPoly(CV_POLY_APPROX_DP) on a closed integer contour of count >= 1 points (x,y pairs in src).
-// dst must hold DP_MAX_OUT+1 points, stack count+2 slices.  Returns the vertex count after the
+// dst must hold DP_MAX_OUT+1 points, stack DP_STACK slices.  Returns the vertex count after the
 // collinear clean-up, or DP_MAX_OUT+1 as soon as the result is known to exceed 4 vertices (the
 // clean-up removes at most every second vertex, so more than 8 raw vertices can never become 4).
+// Every slice waiting on the stack ends in at least one vertex, so "vertices so far + slices waiting > 8" already
+// decides that -- which also bounds the stack: it never holds more than DP_MAX_OUT + 1 slices.
 constexpr int DP_MAX_OUT = 8;
+constexpr int DP_STACK = DP_MAX_OUT + 4;
 
 OCVAR_HD int approx_poly_dp(const int* src, int count, double parameter, int* dst, DpSlice* stack) {
     float eps = (float)parameter;  // cvApproxPoly passes the accuracy as float
@@ -541,6 +554,7 @@ OCVAR_HD int approx_poly_dp(const int* src, int count, double parameter, int* ds
         } else {
             right.end = slice.end;
             slice.end = right.start;
+            if (new_count + top + 2 > DP_MAX_OUT) return DP_MAX_OUT + 1;
             stack[top++] = right;
             stack[top++] = slice;
         }
