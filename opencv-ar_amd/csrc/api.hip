@@ -98,7 +98,7 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     if ((rc = dev_alloc(c, &w.pool, (size_t)w.cap_pool_ints))) return rc;
     // follower grids (and their slabs) scale with the batch: a one-frame context (the reference's per-frame call) does not
     // need -- or pay for -- the 512 + 1024 workgroups that keep a 2048-frame batch busy
-    w.max_mid_blocks = (int)std::min<size_t>(MID_BLOCKS_MAX, std::max<size_t>(32, B * 8));
+    w.max_mid_blocks = (int)std::min<size_t>(MID_BLOCKS_MAX, std::max<size_t>(32, B));
     w.max_long_blocks = (int)std::min<size_t>(LONG_BLOCKS_MAX, std::max<size_t>(32, B * 8));
     if ((rc = dev_alloc(c, &w.slab, (size_t)w.max_mid_blocks * 256 * SLAB_STRIDE))) return rc;
     if ((rc = dev_alloc(c, &w.slab3, (size_t)w.max_long_blocks * 4 * SLAB3_STRIDE))) return rc;
@@ -584,10 +584,11 @@ extern "C" int ocvar_hip_debug_calibrate(OcvarHip* c, size_t bytes) {
 extern "C" int ocvar_hip_counters(OcvarHip* c, long long* out, int n) {
     if (!c || !out || n < 1 || c->pending) return OCVAR_E_ARG;
     const int* h = c->h_counters;
-    long long v[6] = {h[CNT_FRAME_CANDS], h[CNT_CROP_ROIS], h[CNT_CROP_TILES], h[CNT_CROP_CANDS],
+    long long v[12] = {h[CNT_FRAME_CANDS], h[CNT_CROP_ROIS], h[CNT_CROP_TILES], h[CNT_CROP_CANDS],
                       (long long)*reinterpret_cast<const unsigned long long*>(h + CNT_CROP_PIXELS),
-                      (long long)*reinterpret_cast<const unsigned long long*>(h + CNT_POOL_INTS)};
+                      (long long)*reinterpret_cast<const unsigned long long*>(h + CNT_POOL_INTS),
+                      h[CNT_MID_F], h[CNT_MID_C], h[CNT_LONG_F], h[CNT_LONG_C], h[22], h[23]};
     int k = 0;
-    for (; k < 6 && k < n; k++) out[k] = v[k];
+    for (; k < 12 && k < n; k++) out[k] = v[k];
     return k;
 }

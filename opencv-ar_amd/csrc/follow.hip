@@ -164,7 +164,6 @@ constexpr int DP_DST = 2 * (DP_MAX_OUT + 1);
 
 // Per-wave LDS scratch of the finishing code.
 struct WaveScratch {
-    unsigned pts[LDS_PTS];
     DpSlice stack[DP_STACK];
     int dst[DP_DST];
 };
@@ -337,16 +336,17 @@ __device__ __forceinline__ int wave_approx_dp(const unsigned* src, int count, do
 }
 
 // Statistics + approximation + filter + publication of one stored border (npts packed points at gsrc in global memory)
-// by the whole wave.  STAGE: the points fit the wave's LDS scratch (npts <= LDS_PTS).  Returns whether a quad was published.
+// by the whole wave.  STAGE: the points fit the wave's LDS staging area lpts (npts <= LDS_PTS).  Returns whether a quad
+// was published.
 template <bool CROP, bool STAGE>
 __device__ __forceinline__ bool wave_finish_packed(const Workspace& ws, const StartCand c, const PlaneRef& pl, const unsigned* gsrc, int npts,
-                                                   WaveScratch* sc) {
+                                                   unsigned* lpts, WaveScratch* sc) {
     const int lane = threadIdx.x & 63;
     if (npts < 4) return false;
     unsigned lo = 0xffffffffu, hi = 0u;
     for (int i = lane; i < npts; i += 64) {
         const unsigned p = gsrc[i];
-        if (STAGE) sc->pts[i] = p;
+        if (STAGE) lpts[i] = p;
         lo = pk_min(lo, p);
         hi = pk_max(hi, p);
     }
@@ -355,7 +355,7 @@ __device__ __forceinline__ bool wave_finish_packed(const Workspace& ws, const St
     const int bw = px_of(hi) - px_of(lo), bh = py_of(hi) - py_of(lo);
     if (!((long long)bw * bh > 500)) return false;   // worth_approximating: the quad filter needs |area| > 500
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    const unsigned* src = STAGE ? sc->pts : gsrc;
+    const unsigned* src = STAGE ? lpts : gsrc;
     double per = 0.0;
     for (int i = lane; i < npts; i += 64) {
         const unsigned p = src[i], q = src[i == 0 ? npts - 1 : i - 1];
@@ -532,6 +532,7 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
     const int wave = uni((int)(threadIdx.x >> 6));
     const unsigned long long below = (1ull << lane) - 1ull;
     unsigned* wave_slabs = reinterpret_cast<unsigned*>(ws.slab) + ((size_t)blockIdx.x * blockDim.x + uni((int)(threadIdx.x & ~63u))) * SLAB_STRIDE;
+    static_assert(64 * POINT_ROW >= LDS_PTS, "the staging area of the approximation aliases the (flushed) point rows");
     unsigned* my_row = parked[wave] + lane * POINT_ROW;
     const unsigned* wave_rows = parked[wave];
     int flushed = 0;     // points of this lane's walk already in its slab
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
             const int nl = __builtin_amdgcn_readlane(slab_npts, L);
             const unsigned* sl = wave_slabs + (size_t)L * SLAB_STRIDE;
             const PlaneRef pll = plane_of<CROP>(ws, cl.roi);
-            if (!(ws.dbg & 1)) wave_finish_packed<CROP, true>(ws, cl, pll, sl, nl, &scratch[wave]);
+            if (!(ws.dbg & 1)) wave_finish_packed<CROP, true>(ws, cl, pll, sl, nl, parked[wave], &scratch[wave]);
         }
         // budget exhausted: queue for the wave tier
         const unsigned long long mask = __ballot(route == 1);
@@ -820,6 +821,7 @@ template <bool CROP>
 __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
     __shared__ __attribute__((aligned(16))) uint8_t tiles[4][TILE * TILE];
     __shared__ WaveScratch scratch[4];
+    __shared__ unsigned staged[4][LDS_PTS];
     const StartCand* longs = CROP ? ws.long_crop : ws.long_frame;
     int n = ws.counters[CROP ? CNT_LONG_C : CNT_LONG_F];
     if (n > ws.cap_long) n = ws.cap_long;
@@ -871,15 +873,15 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
                     const LeanTrace lt2 = trace_lean_tiled(t, c.pos, c.is_hole, big, lt.npts, 4 * uni(pl.plane) + 16);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                     if (lt2.status == TRACE_OK && lt2.npts == lt.npts) {
-                        wave_finish_packed<CROP, false>(ws, c, pl, reinterpret_cast<const unsigned*>(big), lt2.npts, &scratch[wave]);
+                        wave_finish_packed<CROP, false>(ws, c, pl, reinterpret_cast<const unsigned*>(big), lt2.npts, staged[wave], &scratch[wave]);
                     } else if (lane == 0) {
                         atomicOr(ws.counters + CNT_ERR, ERR_TRACE_OVERRUN);
                     }
                 }
             } else {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // points stored by other lanes of this wave (same CU: L1 is coherent)
-                if (lt.npts <= LDS_PTS) wave_finish_packed<CROP, true>(ws, c, pl, reinterpret_cast<const unsigned*>(slab), lt.npts, &scratch[wave]);
-                else wave_finish_packed<CROP, false>(ws, c, pl, reinterpret_cast<const unsigned*>(slab), lt.npts, &scratch[wave]);
+                if (lt.npts <= LDS_PTS) wave_finish_packed<CROP, true>(ws, c, pl, reinterpret_cast<const unsigned*>(slab), lt.npts, staged[wave], &scratch[wave]);
+                else wave_finish_packed<CROP, false>(ws, c, pl, reinterpret_cast<const unsigned*>(slab), lt.npts, staged[wave], &scratch[wave]);
             }
         }
     }
