@@ -63,6 +63,38 @@ __device__ __forceinline__ unsigned byte_of(unsigned v, int j) { return (v >> (8
 // BGR2GRAY with 8-bit coefficient halves: 1868 = 7*256+76, 9617 = 37*256+145, 4899 = 19*256+35
 __device__ __forceinline__ unsigned grey_px(unsigned w, unsigned khi, unsigned klo) { return (dot4(w, khi, 0) * 256u + dot4(w, klo, 8192u)) >> 14; }
 
+// ---- neighbour masks and border starts by table ---------------------------------------------------------------------
+// A lane's 4 threshold bits of one row plus the bits next to them form a 7-bit window: bit 0 = column c0-1 (the left
+// lane's pixel 3), bits 1..4 = the lane's pixels 0..3, bits 5, 6 = columns c0+4, c0+5 (the right lane's pixels 0, 1).
+// What a row contributes to the 8-neighbour masks of the 4 pixels -- as the row above (NE N NW), the pixels' own row
+// (E W) and the row below (SW S SE) -- and to the border-start tests depends on that window only, so it is read from a
+// 128-entry table in LDS (one ds_read_b128 per lane and row) instead of being spread out with multiplications:
+//   x: mask bytes of the 4 pixels contributed as the row above      y: ... as their own row      z: ... as the row below
+//   w: start nibbles (bit p = pixel p).  Low half, the row as the pixels' own row:  [0] centre & ~W   [1] E   [2] W & ~centre
+//      [3] ~E.  High half, the row as the row above:  [4] ~(NW | N | NE)   [5] the pixel above E's east neighbour
+//      [6] N   [7] ~NE.  With t = low(own row) & high(row above), t & ~(t >> 4) has the outer starts in nibble 0
+//      (centre & ~W & ~NW & ~N & ~NE & ~(E & NEE)) and the hole starts in nibble 2 (W & ~centre & N & (E | NE)):
+//      the necessary local conditions for being the raster-first pixel of a region (see march_unit).
+__device__ __forceinline__ uint4 mask_table_entry(unsigned w) {
+    uint4 t = make_uint4(0u, 0u, 0u, 0u);
+    unsigned mA = 0, mB = 0, mC = 0, uA = 0, uB = 0, uC = 0, uD = 0;
+    for (unsigned p = 0; p < 4; p++) {
+        const unsigned xm = (w >> p) & 1u, x0 = (w >> (p + 1)) & 1u, xp = (w >> (p + 2)) & 1u, xpp = (w >> (p + 3)) & 1u;
+        t.x |= ((xp << 1) | (x0 << 2) | (xm << 3)) << (8 * p);   // NE N NW
+        t.y |= (xp | (xm << 4)) << (8 * p);                      // E W
+        t.z |= ((xm << 5) | (x0 << 6) | (xp << 7)) << (8 * p);   // SW S SE
+        mA |= (x0 & ~xm & 1u) << p;
+        mB |= xp << p;
+        mC |= (xm & ~x0 & 1u) << p;
+        uA |= (~(xm | x0 | xp) & 1u) << p;
+        uB |= xpp << p;
+        uC |= x0 << p;
+        uD |= xp << p;
+    }
+    t.w = mA | (mB << 4) | (mC << 8) | ((~mB & 15u) << 12) | (uA << 16) | (uB << 20) | (uC << 24) | ((~uD & 15u) << 28);
+    return t;
+}
+
 struct MarchOut {
     uint8_t* gray;          // frame mode: grey plane of this frame (stride gray_stride), else null
     long long gray_stride;
@@ -78,7 +110,7 @@ struct MarchOut {
 // One work unit: strip `strip` of an (sw x sh) ROI, output rows [Y0, Y1).
 template <bool BGR>
 __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int sh, int strip, int Y0, int Y1, const MarchOut& o,
-                           unsigned* stage, unsigned* rowbuf /* LDS, 8 rows x 64 lanes */) {
+                           unsigned* stage, unsigned* rowbuf /* LDS, 8 rows x 64 lanes */, const uint4* tab /* LDS, mask_table_entry */) {
     const int lane = threadIdx.x & 63;
     const int XS = strip * SV - 4 * HL;
     const int c0 = XS + 4 * lane;
@@ -103,11 +135,11 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     // per-lane byte offsets (unsigned: the row bases are wave-uniform, so loads/stores can use the SGPR-base + 32-bit VGPR offset form)
     const unsigned src_off = fast ? (unsigned)(c0 * (BGR ? 3 : 1)) : 0u;
     const unsigned out_off = out_lane ? (unsigned)c0 : 0u;
-    const unsigned right_bits = lane == 63 - HR ? 0x202020u : 0x202060u;   // the last output lane's x+2 bit (row above) is not computed
+    const unsigned rmask = lane == 63 - HR ? 1u : 3u;   // the last output lane's x+2 bit (row above) is not computed
     unsigned colmask = 0;  // which of the lane's 4 columns lie inside cvFindContours' zeroed frame
     for (int j = 0; j < 4; j++) colmask |= (c0 + j >= 1 && c0 + j <= sw - 2) ? (1u << j) : 0u;
-    unsigned pxmask = 0;   // bit 8j: the lane's pixel j is an output pixel of this strip
-    for (int j = 0; j < 4; j++) pxmask |= (out_lane && c0 + j < sw) ? (1u << (8 * j)) : 0u;
+    unsigned pxsel = 0;    // bits j and 8+j: the lane's pixel j is an output pixel of this strip (outer / hole start nibbles)
+    for (int j = 0; j < 4; j++) pxsel |= (out_lane && c0 + j < sw) ? (0x101u << j) : 0u;
 
     // Mask rows are collected in LDS, 8 rows at a time, and written as whole 16x8-pixel tiles (128 contiguous bytes, 32
     // per lane) -- a row at a time would be 16-byte pieces of 15 different cache lines per wave, and on this hardware a
@@ -207,7 +239,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     unsigned we[7], wo[7];                   // the last 7 (virtual) pyrUp rows, newest last: even columns (u0|u2<<16), odd (u1|u3<<16)
 #pragma unroll
     for (int k = 0; k < 7; k++) we[k] = wo[k] = 0;
-    unsigned binw = 0;                       // threshold bits of rows y-2, y-1, y in bytes 0,1,2 (bits 1..4 of each)
+    unsigned m_prev = 0, u_prev = 0, x_prev = 0;   // mask of row y-1 still without its row below; what row y-1 gives to the row below it; its start nibbles
 
     Raw nxt = fetch(v_first);
     for (int v = v_first; v <= v_last; v++) {
@@ -305,48 +337,43 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                         const unsigned S2 = dot2(Vol, K2(0, 8), dot2(Ve, K2(28, 72), dot2(Vo, K2(56, 56), dot2(Ver, K2(28, 0), dot2(Vor, K2(8, 0), C0)))));
                         const unsigned S3 = dot2(Ve, K2(8, 56), dot2(Vo, K2(28, 72), dot2(Ver, K2(56, 8), dot2(Vor, K2(28, 0), C0))));
                         const unsigned ce = we[3], co = wo[3];   // pyrUp row y itself: the threshold's source
-                        nib = (int)S3 < (int)(co & 0xffff0000u) ? 1u : 0u;
-                        nib = nib + nib + ((int)S2 < (int)(ce & 0xffff0000u) ? 1u : 0u);
-                        nib = nib + nib + ((int)S1 < (int)(co << 16) ? 1u : 0u);
-                        nib = nib + nib + ((int)S0 < (int)(ce << 16) ? 1u : 0u);
+                        // nib = 2 * nib + (S < src << 16), pixel 3 first: one compare and one add-with-carry per pixel
+#define OCVAR_PUSH_BIT(S, RHS) asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nib) : "v"(S), "v"(RHS) : "vcc")
+                        OCVAR_PUSH_BIT(S3, co & 0xffff0000u);
+                        OCVAR_PUSH_BIT(S2, ce & 0xffff0000u);
+                        OCVAR_PUSH_BIT(S1, co << 16);
+                        OCVAR_PUSH_BIT(S0, ce << 16);
+#undef OCVAR_PUSH_BIT
                         nib &= colmask;
                     }
-                    binw = (binw >> 8) | (nib << 17);   // rows y-2, y-1, y at bytes 0, 1, 2; a row's 4 bits at bits 1..4 of its byte
+                    // Row y's window -> table: its share of the masks of rows y-1, y, y+1 and its start nibbles.
+                    const unsigned wdw = (nib << 1) | (up1(nib) >> 3) | ((down1(nib) & rmask) << 5);
+                    const uint4 T = tab[wdw];
+                    const unsigned nbr4 = m_prev | T.z;        // row y-1: E | NE N NW | W | SW S SE complete
+                    unsigned st = T.w & (x_prev >> 16);        // row y's own nibbles & row y-1's "row above" nibbles
+                    m_prev = u_prev | T.y;
+                    u_prev = T.x;
+                    x_prev = T.w;
+                    st = st & ~(st >> 4) & pxsel;              // bits 0..3: outer starts, bits 8..11: hole starts of row y
                     const int yr = y - 1;
-                    if (yr < Y0 || yr >= Y1) continue;
-                    // Row yr's 8-neighbour masks from threshold rows yr-1, yr, yr+1.  Each byte of Wn becomes a 6-bit window
-                    // (columns c0-1 .. c0+4) with the edge bits of the neighbour lanes; a multiplication by 0x204081 lays
-                    // copies shifted by 7, 14, 21 side by side so that byte p holds (window >> p): bits 0,1,2 = x-1, x, x+1 of
-                    // pixel p.  The row above goes through a bit reversal because directions run counter-clockwise.
-                    const unsigned Wn = binw | ((up1(binw) >> 4) & 0x010101u) | ((down1(binw) << 4) & right_bits);   // row above: one more column (x+2 of pixel 3)
-                    const unsigned Ms = __umul24((Wn >> 8) & 0x3fu, 0x204081u);
-                    const unsigned Bs = __umul24((Wn >> 11) & (0x3fu << 5), 0x204081u) & 0xe0e0e0e0u;   // SW S SE at bits 5..7
-                    const unsigned As = __umul24(__builtin_bitreverse32(Wn) >> 26, 0x204081u) & 0x07070707u;   // byte 3-p: NE, N, NW of pixel p
-                    const unsigned centre = (Ms >> 1) & 0x01010101u, west = Ms & 0x01010101u;
-                    const unsigned nbr4 = ((Ms >> 2) & 0x01010101u) | (__builtin_amdgcn_perm(As, As, 0x00010203u) << 1) | (west << 4) |
-                                          Bs;   // E | NE N NW | W | SW S SE
-                    rowbuf[(yr & 7) * 64 + lane] = nbr4;
-                    if ((yr & 7) == 7 || yr == Y1 - 1) flush_rows(yr);
-                    // Plausible border starts (sparse): necessary local conditions for being the raster-first pixel of a region.
-                    // Outer: foreground pixel whose W, NW, N, NE are background -- and not (E foreground and the pixel above E's
-                    // east neighbour foreground: that one belongs to the same 8-connected component and comes earlier).
+                    if (yr >= Y0 && yr < Y1) {
+                        rowbuf[(yr & 7) * 64 + lane] = nbr4;
+                        if ((yr & 7) == 7 || yr == Y1 - 1) flush_rows(yr);
+                    }
+                    // Plausible border starts of row y (sparse): necessary local conditions for being the raster-first pixel of
+                    // a region.  Outer: foreground pixel whose W, NW, N, NE are background -- and not (E foreground and the pixel
+                    // above E's east neighbour foreground: that one belongs to the same 8-connected component and comes earlier).
                     // Hole: background pixel whose W and N are foreground -- and E or NE foreground (if both are background they
                     // belong to the same 4-connected background region and NE comes earlier).
-                    const unsigned upper = nbr4 & 0x1e1e1e1eu;
-                    const unsigned any_upper = ((upper + 0x7f7f7f7fu) >> 7) & 0x01010101u;
-                    const unsigned nee = (__umul24(Wn & 0x7fu, 0x204081u) >> 3) & nbr4;   // bit 0 of byte p: E(p) & row above at x+2
-                    const unsigned outer = centre & ~any_upper & ~nee & pxmask;
-                    const unsigned hole = west & (nbr4 >> 2) & (nbr4 | (nbr4 >> 1)) & ~centre & pxmask;
-                    const unsigned types = outer | (hole << 1);   // per pixel byte: 1 = outer start, 2 = hole start
-                    if (__ballot(types != 0) == 0) continue;
+                    if (y < Y0 || y >= Y1 || __ballot(st != 0) == 0) continue;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const int type = (int)((types >> (8 * j)) & 3u) - 1;
+                        const int type = ((st >> j) & 1u) ? 0 : ((st >> (8 + j)) & 1u) ? 1 : -1;
                         const unsigned long long mask = __ballot(type >= 0);
                         if (!mask) continue;
                         const int n = __popcll(mask);
                         if (staged + n > MARCH_STAGE) flush();
-                        if (type >= 0) stage[staged + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)(yr * o.ns + c0 + j) | ((unsigned)type << 31);
+                        if (type >= 0) stage[staged + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)(y * o.ns + c0 + j) | ((unsigned)type << 31);
                         staged += n;
                     }
                 }
@@ -361,6 +388,9 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
 __global__ __launch_bounds__(256) void binarise_frames_kernel(Workspace ws, const uint8_t* bgr, int row_stride, size_t frame_stride) {
     __shared__ unsigned stage[4][MARCH_STAGE];
     __shared__ __attribute__((aligned(16))) unsigned rowbuf[4][8 * 64];
+    __shared__ uint4 tab[128];
+    if (threadIdx.x < 128) tab[threadIdx.x] = mask_table_entry(threadIdx.x);
+    __syncthreads();
     const int unit = blockIdx.x * 4 + wave_uniform((int)(threadIdx.x >> 6));
     const int per_frame = ws.frame_strips * ws.frame_chunks;
     if (unit >= per_frame * ws.n_frames) return;
@@ -378,7 +408,7 @@ __global__ __launch_bounds__(256) void binarise_frames_kernel(Workspace ws, cons
     o.n_cands = ws.counters + CNT_FRAME_CANDS;
     o.cap_cands = ws.cap_frame_cands;
     o.err = ws.counters + CNT_ERR;
-    march_unit<true>(bgr + (size_t)f * frame_stride, row_stride, ws.sw, ws.sh, strip, Y0, Y1, o, stage[wave_uniform((int)(threadIdx.x >> 6))], rowbuf[wave_uniform((int)(threadIdx.x >> 6))]);
+    march_unit<true>(bgr + (size_t)f * frame_stride, row_stride, ws.sw, ws.sh, strip, Y0, Y1, o, stage[wave_uniform((int)(threadIdx.x >> 6))], rowbuf[wave_uniform((int)(threadIdx.x >> 6))], tab);
 }
 
 // Odd width / height: the last column / row lies outside the even working size (opencvar.cpp:158) but is still
@@ -413,6 +443,9 @@ __global__ __launch_bounds__(256) void grey_writeback_kernel(Workspace ws, uint8
 __global__ __launch_bounds__(256) void binarise_crops_kernel(Workspace ws) {
     __shared__ unsigned stage[4][MARCH_STAGE];
     __shared__ __attribute__((aligned(16))) unsigned rowbuf[4][8 * 64];
+    __shared__ uint4 tab[128];
+    if (threadIdx.x < 128) tab[threadIdx.x] = mask_table_entry(threadIdx.x);
+    __syncthreads();
     int n_units = ws.counters[CNT_CROP_TILES];
     if (n_units > ws.cap_crop_tiles) n_units = ws.cap_crop_tiles;
     const int wave = wave_uniform((int)(threadIdx.x >> 6));
@@ -440,7 +473,7 @@ __global__ __launch_bounds__(256) void binarise_crops_kernel(Workspace ws) {
         o.n_cands = ws.counters + CNT_CROP_CANDS;
         o.cap_cands = ws.cap_crop_cands;
         o.err = ws.counters + CNT_ERR;
-        march_unit<false>(src, ws.W, r.sw, r.sh, td.x0, td.y0, Y1, o, stage[wave], rowbuf[wave]);
+        march_unit<false>(src, ws.W, r.sw, r.sh, td.x0, td.y0, Y1, o, stage[wave], rowbuf[wave], tab);
     }
 }
 
