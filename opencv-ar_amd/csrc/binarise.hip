@@ -132,6 +132,20 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         xr2 = reflect101(c0 + 2, sw) * (BGR ? 3 : 1);
         xr3 = reflect101(c0 + 3, sw) * (BGR ? 3 : 1);
     }
+    // Grey sources (crops): every lane loads ONE unaligned dword per row and permutes its bytes -- also the lanes that hold
+    // reflected columns.  With BORDER_REFLECT_101 a lane left of column 0 holds columns -c0 .. -c0-3, a lane right of
+    // column sw-1 holds 2sw-2-c0 .. 2sw-5-c0: four contiguous source bytes in reverse order; the lane that straddles the
+    // right edge (sw - c0 == 2: sw is even, c0 a multiple of 4) holds c0, c0+1, c0, c0-1.  (The byte loads of the generic
+    // path sit in a branch, which makes every row wait for its own loads instead of running a row ahead: a crop has edge
+    // lanes on both sides of every work unit, and its binarise kernel was latency-bound by that.)
+    const bool grey_plan = !BGR && sw >= 32;   // single reflection, every offset inside the row
+    unsigned goff = 0, gsel = 0x03020100u;
+    if (grey_plan && needed) {
+        if (c0 + 3 < 0) { goff = (unsigned)(-c0 - 3); gsel = 0x00010203u; }
+        else if (c0 >= sw) { goff = (unsigned)(2 * sw - 5 - c0); gsel = 0x00010203u; }
+        else if (c0 + 3 >= sw) { goff = (unsigned)(c0 - 1); gsel = 0x00010201u; }
+        else goff = (unsigned)c0;
+    }
     // per-lane byte offsets (unsigned: the row bases are wave-uniform, so loads/stores can use the SGPR-base + 32-bit VGPR offset form)
     const unsigned src_off = fast ? (unsigned)(c0 * (BGR ? 3 : 1)) : 0u;
     const unsigned out_off = out_lane ? (unsigned)c0 : 0u;
@@ -193,8 +207,15 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     struct Raw { unsigned d0, d1, d2; };
     auto fetch = [&](int v) -> Raw {
         Raw r = {0u, 0u, 0u};
-        if (!needed) return r;
         const uint8_t* row = src + wave_uniform64((long long)reflect101(v, sh) * src_stride);
+        if (!BGR && grey_plan) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(row + goff);
+            const unsigned* p = reinterpret_cast<const unsigned*>(a & ~(uintptr_t)3);
+            const unsigned d = alignb(p[1], p[0], (unsigned)(a & 3));
+            r.d0 = __builtin_amdgcn_perm(d, d, gsel);
+            return r;
+        }
+        if (!needed) return r;
         if (fast) {
             if (BGR) {
                 if (aligned) {
@@ -292,20 +313,22 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                     Uo = ((as_us2(rBo) + as_us2(rCo)) * (unsigned short)4 + (unsigned short)32) >> (unsigned short)6;
                 }
                 // BORDER_REPLICATE of the Gaussian: columns < 0 take column 0, columns >= sw take column sw-1
-                if (left_edge || right_edge) {
-                    unsigned U4 = as_u32(Ue) | (as_u32(Uo) << 8);
-                    if (left_edge) {
-                        const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)U4, HL) & 255u;   // column 0
-                        if (lane < HL) U4 = e * 0x01010101u;
+                // (packed pairs: Ue = (u0, u2), Uo = (u1, u3); the edge value is wave-uniform, the selects use constant lane masks)
+                if (left_edge) {
+                    const unsigned e2 = ((unsigned)__builtin_amdgcn_readlane((int)as_u32(Ue), HL) & 0xffffu) * 0x10001u;   // column 0
+                    Ue = as_us2(lane < HL ? e2 : as_u32(Ue));
+                    Uo = as_us2(lane < HL ? e2 : as_u32(Uo));
+                }
+                if (right_edge) {   // column sw-1 is pixel j1 (1 or 3: sw is even) of lane L1
+                    const unsigned o1 = (unsigned)__builtin_amdgcn_readlane((int)as_u32(Uo), L1 < 0 ? 0 : L1);
+                    const unsigned e = j1 == 1 ? (o1 & 0xffffu) : (o1 >> 16);
+                    const unsigned e2 = e * 0x10001u;
+                    Ue = as_us2(lane > L1 ? e2 : as_u32(Ue));
+                    Uo = as_us2(lane > L1 ? e2 : as_u32(Uo));
+                    if (j1 == 1) {   // pixels 2, 3 of lane L1 lie beyond the edge
+                        Ue = as_us2(lane == L1 ? ((as_u32(Ue) & 0xffffu) | (e << 16)) : as_u32(Ue));
+                        Uo = as_us2(lane == L1 ? ((as_u32(Uo) & 0xffffu) | (e << 16)) : as_u32(Uo));
                     }
-                    if (right_edge) {
-                        const unsigned e = byte_of((unsigned)__builtin_amdgcn_readlane((int)U4, L1 < 0 ? 0 : L1), j1);
-                        if (lane > L1) U4 = e * 0x01010101u;
-                        else if (lane == L1)
-                            for (int j = j1 + 1; j < 4; j++) U4 = (U4 & ~(255u << (8 * j))) | (e << (8 * j));
-                    }
-                    Ue = as_us2(U4 & 0x00ff00ffu);
-                    Uo = as_us2((U4 >> 8) & 0x00ff00ffu);
                 }
                 // rows above 0 / below sh-1 replicate row 0 / sh-1; one more virtual row flushes the last mask row
                 const int vlo = (u == 0) ? -3 : u, vhi = (u == sh - 1) ? sh + 3 : u;
