@@ -132,20 +132,23 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         xr2 = reflect101(c0 + 2, sw) * (BGR ? 3 : 1);
         xr3 = reflect101(c0 + 3, sw) * (BGR ? 3 : 1);
     }
-    // Grey sources (crops): every lane loads ONE unaligned dword per row and permutes its bytes -- also the lanes that hold
-    // reflected columns.  With BORDER_REFLECT_101 a lane left of column 0 holds columns -c0 .. -c0-3, a lane right of
-    // column sw-1 holds 2sw-2-c0 .. 2sw-5-c0: four contiguous source bytes in reverse order; the lane that straddles the
-    // right edge (sw - c0 == 2: sw is even, c0 a multiple of 4) holds c0, c0+1, c0, c0-1.  (The byte loads of the generic
-    // path sit in a branch, which makes every row wait for its own loads instead of running a row ahead: a crop has edge
-    // lanes on both sides of every work unit, and its binarise kernel was latency-bound by that.)
-    const bool grey_plan = !BGR && sw >= 32;   // single reflection, every offset inside the row
+    // Load plan: every lane loads its 4 pixels with ONE (unaligned) load per row -- 4 bytes grey, 12 bytes BGR -- also the
+    // lanes that hold reflected columns, whose 4 (grey) bytes are then permuted.  With BORDER_REFLECT_101 a lane left of
+    // column 0 holds columns -c0 .. -c0-3, a lane right of column sw-1 holds 2sw-2-c0 .. 2sw-5-c0: four contiguous source
+    // pixels in reverse order; the lane that straddles the right edge (sw - c0 == 2: sw is even, c0 a multiple of 4) holds
+    // c0, c0+1, c0, c0-1 and loads c0-2 .. c0+1.  (The byte loads of the generic path sit in a divergent branch, which makes
+    // every row wait for its own loads instead of running a row ahead: a crop has edge lanes on both sides of every work
+    // unit, and its binarise kernel was latency-bound by that.)  No byte outside columns 0 .. sw-1 of the row is read.
+    const bool plan = sw >= 32;   // single reflection, every offset inside the row
     unsigned goff = 0, gsel = 0x03020100u;
-    if (grey_plan && needed) {
+    if (plan && needed) {
         if (c0 + 3 < 0) { goff = (unsigned)(-c0 - 3); gsel = 0x00010203u; }
         else if (c0 >= sw) { goff = (unsigned)(2 * sw - 5 - c0); gsel = 0x00010203u; }
-        else if (c0 + 3 >= sw) { goff = (unsigned)(c0 - 1); gsel = 0x00010201u; }
+        else if (c0 + 3 >= sw) { goff = (unsigned)(c0 - 2); gsel = 0x01020302u; }
         else goff = (unsigned)c0;
     }
+    goff *= BGR ? 3u : 1u;
+    const bool permuted = left_edge || right_edge;   // wave-uniform: some lane of this strip holds reflected columns
     // per-lane byte offsets (unsigned: the row bases are wave-uniform, so loads/stores can use the SGPR-base + 32-bit VGPR offset form)
     const unsigned src_off = fast ? (unsigned)(c0 * (BGR ? 3 : 1)) : 0u;
     const unsigned out_off = out_lane ? (unsigned)c0 : 0u;
@@ -208,11 +211,8 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     auto fetch = [&](int v) -> Raw {
         Raw r = {0u, 0u, 0u};
         const uint8_t* row = src + wave_uniform64((long long)reflect101(v, sh) * src_stride);
-        if (!BGR && grey_plan) {
-            const uintptr_t a = reinterpret_cast<uintptr_t>(row + goff);
-            const unsigned* p = reinterpret_cast<const unsigned*>(a & ~(uintptr_t)3);
-            const unsigned d = alignb(p[1], p[0], (unsigned)(a & 3));
-            r.d0 = __builtin_amdgcn_perm(d, d, gsel);
+        if (plan) {
+            __builtin_memcpy(&r, row + goff, BGR ? 12 : 4);   // unaligned global_load_dword / dwordx3
             return r;
         }
         if (!needed) return r;
@@ -266,7 +266,8 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     for (int v = v_first; v <= v_last; v++) {
         const Raw cur = nxt;
         if (v < v_last) nxt = fetch(v + 1);  // issue the next row's loads before this row's arithmetic
-        const unsigned g = to_grey(cur);
+        unsigned g = to_grey(cur);
+        if (plan && permuted) g = __builtin_amdgcn_perm(g, g, gsel);
         if (BGR && o.gray && out_lane && v >= Y0 && v < Y1) {  // rows [Y0,Y1) are real rows, each loaded exactly once
             uint8_t* q = o.gray + wave_uniform64((long long)v * o.gray_stride) + out_off;
             if (gray_dword) *reinterpret_cast<unsigned*>(q) = g;
