@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the AR-marker detection path (BASELINE.json metric) on N MI355X.
 
-A "step" is one pass of the whole hot path (7 kernels: binarise, follow, order/crops, binarise crops, follow
-crops, decode, dedupe+pose, and the copy-out of the CvarMarker arrays) over one batch of synthetic frames per GPU.
+A "step" is one pass of the whole hot path (11 kernels: binarise, follower tiers 1-3, order/crops, binarise crops,
+follower tiers 1-3 on the crops, decode, dedupe+pose, and the copy-out of the CvarMarker arrays) over one batch of
+synthetic frames per GPU.
 Workload at every N: BASELINE.json configs[2] -- 1920x1080, 16 planted markers/frame, templates 2x2/3x3/4x4.
 Frames are resident in HBM before the timed region.  For N > 1 (one process per GPU, torchrun) frames are
 sharded by frame, there is no data-path collective; the per-rank CvarMarker arrays are gathered to rank 0 over
@@ -24,19 +25,59 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(frames, tpls, cam, budget_s=12.0):
-    """The oracle (CPU restatement of the reference path, oracle/) timed on a bounded sample of the same frames,
-    single thread -- the reference is single-threaded.  Reported beside the GPU number, never part of it."""
+def cpu_baseline(frames, tpls, cam, budget_s=10.0):
+    """The oracle (CPU restatement of the reference path, oracle/) timed on a bounded sample of the same frames on this
+    box's host cores: all hardware threads, frame-parallel (std::thread inside liboracle.so), and one thread -- the
+    reference itself is single-threaded.  Reported beside the GPU number, never part of it."""
     import helpers as H
-    H.oracle()
-    n, t0 = 0, time.perf_counter()
-    while n < len(frames) and (n < 3 or time.perf_counter() - t0 < budget_s):
-        H.oracle_registration(frames[n], tpls, cam)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} of the benchmark's 1920x1080 frames, oracle (CPU restatement; reference not runnable "
-                      f"without OpenCV), 1 thread, {dt:.1f} s"}
+    lib = H.oracle()
+    lib.orc_registration_throughput.restype = C.c_longlong
+    lib.orc_registration_throughput.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
+                                                C.c_void_p, C.c_int, C.c_double, C.c_longlong, C.c_void_p, C.c_void_p]
+    frames = np.ascontiguousarray(frames)
+    n, h, w, _ = frames.shape
+
+    def run(threads, budget):
+        sec, used = C.c_double(0), C.c_int(0)
+        done = lib.orc_registration_throughput(frames.ctypes.data, n, w, h, 3 * w, 3 * w * h, C.byref(tpls), len(tpls),
+                                               C.byref(cam), threads, budget, 1 << 40, C.byref(sec), C.byref(used))
+        return done, sec.value, used.value
+
+    d1, s1, _ = run(1, min(6.0, budget_s))
+    dn, sn, cores = run(0, budget_s)
+    return {"value": round(dn / sn, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{dn} runs over {n} of the benchmark's {w}x{h} frames in {sn:.1f} s, oracle (CPU restatement; the reference "
+                      f"is not runnable without OpenCV), frame-parallel over {cores} host threads",
+            "one_thread": {"value": round(d1 / s1, 3), "unit": "frames/s", "cores": 1,
+                           "sample": f"{d1} frames in {s1:.1f} s, one thread (the reference is single-threaded)"}}
+
+
+def call_latency(config_id, calls=60):
+    """One frame per call through the reference's own entry point (cvarArMultRegistration of libopencv-ar.so, host frame
+    in, markers out, frame greyed in place): the C++ sample samples/artest_latency.cpp as a child process."""
+    import subprocess
+    import opencv_ar_amd as oa
+    exe = os.path.join(os.path.dirname(oa.LIB_DIR), "bin", "artest_latency")
+    try:
+        out = subprocess.run([exe, oa.TEMPLATE_DIR, str(config_id), str(calls)], capture_output=True, text=True, timeout=300)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:   # reported, never fatal for the throughput line
+        return {"error": repr(e)}
+
+
+def check_results(det, d_frames_ptr, cfg, truths, W, Hh, n):
+    """Sanity check outside the timed region: every planted (unoccluded) marker of the first n frames is decoded -- one
+    pre-dedupe candidate with a matching code whose corners coincide with the planted quad (the CvarMarker arrays themselves
+    keep at most one marker per template and frame: the reference's `||` dedupe, opencvar.cpp:784-785)."""
+    det.detect_device(d_frames_ptr, W, Hh, n)
+    for f in range(n):
+        planted = [t for t in truths[f] if not t["occluded"]]
+        hits = [c for c in det.debug_candidates(f) if c.orient > 0]
+        assert len(hits) >= len(planted), f"frame {f}: {len(hits)} decoded markers, {len(planted)} planted"
+        for t in planted:
+            tc = t["corner"]
+            ok = any(all(np.abs(tc - np.array(c.square).reshape(4, 2)[k]).sum(axis=1).min() <= 8 for k in range(4)) for c in hits)
+            assert ok, f"frame {f}: planted marker at {tc.tolist()} not among the decoded candidates"
 
 
 def main():
@@ -46,9 +87,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8192, help="frames per GPU per step (over all streams)")
     ap.add_argument("--streams", type=int, default=4, help="independent detector contexts / HIP streams per GPU; the batch is split over them")
-    ap.add_argument("--unique", type=int, default=16, help="distinct synthetic frames per GPU (tiled to the batch)")
+    ap.add_argument("--unique", type=int, default=256, help="distinct synthetic frames per GPU (tiled to the batch on the device)")
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config id (3 = headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the one-frame-per-call latency leg (child process)")
     args = ap.parse_args()
 
     import torch
@@ -79,7 +121,11 @@ def main():
     W, Hh, B = cfg.width, cfg.height, args.batch
     uniq = max(1, min(args.unique, B))
     # frame index space is sharded by frame: rank r owns frames r, r+world, ...
-    base = np.stack([H.synth_frame(cfg, S.frame_of(rank, world, i), names)[0] for i in range(uniq)])
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:   # the generator is C (ctypes releases the GIL)
+        made = list(ex.map(lambda i: H.synth_frame(cfg, S.frame_of(rank, world, i), names), range(uniq)))
+    base = np.stack([m[0] for m in made])
+    truths = [m[1] for m in made]
     # setup side through the product's own host library (cvarLoadTemplateTag on the PNGs, cvarReadCamera(NULL) +
     # cvarCameraScale); the oracle is only touched by the cpu_baseline leg below
     tpl_list = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, n + ".png") for n in (names or H.TEMPLATE_ORDER)])
@@ -116,11 +162,13 @@ def main():
     frames_done = [0]
     last = {}
 
-    def enqueue(i, n, buf):
-        dets[i].enqueue_device(d_frames.data_ptr() + int(offs[i]) * frame_bytes, W, Hh, n, stream=streams[i].cuda_stream)
+    def enqueue(i, n, buf, skip=0):
+        """context i detects frames [offs[i] + skip, offs[i] + skip + n) of the batch"""
+        o = int(offs[i]) + skip
+        dets[i].enqueue_device(d_frames.data_ptr() + o * frame_bytes, W, Hh, n, stream=streams[i].cuda_stream)
         if world > 1:
-            dets[i].results_to_device(d_res[buf].data_ptr() + int(offs[i]) * S.MAX_MARKERS * S.MARKER_BYTES,
-                                      d_res[buf].data_ptr() + nbytes_m + 4 * int(offs[i]), streams[i].cuda_stream)
+            dets[i].results_to_device(d_res[buf].data_ptr() + o * S.MAX_MARKERS * S.MARKER_BYTES,
+                                      d_res[buf].data_ptr() + nbytes_m + 4 * o, streams[i].cuda_stream)
         last[i] = n
 
     def collect(i, timed):
@@ -140,8 +188,8 @@ def main():
             for i in range(NS):
                 parts[i] = collect(i, timed)
                 n = sub[i] if k < K - 1 else sub[i] - first[i]
-                if n > 0:
-                    enqueue(i, n, (k + 1) % 2)
+                if n > 0:   # the last, partial launch covers the frames the first one left out
+                    enqueue(i, n, (k + 1) % 2, skip=0 if k < K - 1 else first[i])
                 else:
                     last.pop(i)
             if world > 1:   # one gather of the ranks' result blocks per step (the launches that filled this buffer are complete)
@@ -154,6 +202,7 @@ def main():
             last.pop(i)
         return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
 
+    check_results(dets[0], d_frames.data_ptr(), cfg, truths, W, Hh, min(8, uniq, sub[0]))
     if args.warmup > 0:
         markers, counts = run(args.warmup, False)
     if dist is not None:
@@ -207,7 +256,7 @@ def main():
         dom = max(kernels, key=lambda k: stage_ms[k[1]])
         ach = dom[2] / (stage_ms[dom[1]] * 1e-3) / 1e9
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tf):   # HBM bytes per frame from rocprofv3 PMC passes (tools/collect_traffic.py), scaled to a launch
             t = json.load(open(tf)).get(dom[0].split("<")[0] if dom[0].startswith("binarise") else dom[0])
             if t and t.get("width") == W and t.get("height") == Hh:
@@ -239,7 +288,11 @@ def main():
         }
         if not args.no_cpu_baseline:
             tpls = (H.Template * len(tpl_list))(*[H.Template.from_buffer_copy(bytes(t)) for t in tpl_list])
-            out["cpu_baseline"] = cpu_baseline(np.concatenate([base] * ((256 + uniq - 1) // uniq)), tpls, H.Camera.from_buffer_copy(bytes(camera)))
+            out["cpu_baseline"] = cpu_baseline(base[:min(uniq, 256)], tpls, H.Camera.from_buffer_copy(bytes(camera)))
+        if not args.no_latency:
+            lat = call_latency(args.config)
+            out["latency_ms"] = lat.get("median_ms")
+            out["latency"] = lat
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

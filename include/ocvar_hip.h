@@ -112,7 +112,8 @@ int ocvar_hip_debug_calibrate(OcvarHip* ctx, size_t bytes);
  * [6..8] follower tiers 1,2,3 (crops) [9] decode [10] dedupe+pose [11] whole batch.  Returns the number written. */
 int ocvar_hip_stage_ms(OcvarHip* ctx, float* ms, int n);
 /* Work counters of the last batch: [0] frame start candidates [1] crop ROIs [2] crop tiles
- * [3] crop start candidates [4] sum of crop areas (pixels) [5] point-pool ints used. */
+ * [3] crop start candidates [4] sum of crop areas (pixels) [5] point-pool ints used [6],[7] starts handed to follower
+ * tier 2 (frames, crops) [8],[9] borders handed to tier 3 (frames, crops). */
 int ocvar_hip_counters(OcvarHip* ctx, long long* out, int n);
 
 #ifdef __cplusplus

@@ -54,8 +54,35 @@ typedef struct CvMat {
     int cols;
 } CvMat;
 
-typedef struct CvSeq CvSeq;               /* opaque: only passed through */
-typedef struct CvMemStorage CvMemStorage; /* opaque */
+typedef struct CvMemStorage CvMemStorage; /* opaque: only passed through */
+
+/* CvSeq as OpenCV 2.x/3.x lay it out (CV_TREE_NODE_FIELDS + CV_SEQUENCE_FIELDS, types_c.h): a caller compiled against the
+ * real headers finds `total` at offset 40, `elem_size` at 44 and the element blocks behind `first`, so reading
+ * seq->total or walking the blocks (what cvGetSeqElem does) works on the sequences cvarFindSquares returns. */
+typedef struct CvSeqBlock {
+    struct CvSeqBlock* prev;
+    struct CvSeqBlock* next;
+    int start_index;
+    int count;
+    signed char* data;
+} CvSeqBlock;
+
+typedef struct CvSeq {
+    int flags;
+    int header_size;
+    struct CvSeq* h_prev;
+    struct CvSeq* h_next;
+    struct CvSeq* v_prev;
+    struct CvSeq* v_next;
+    int total;
+    int elem_size;
+    signed char* block_max;
+    signed char* ptr;
+    int delta_elems;
+    CvMemStorage* storage;
+    CvSeqBlock* free_blocks;
+    CvSeqBlock* first;
+} CvSeq;
 
 #define IPL_DEPTH_8U 8
 

@@ -274,6 +274,6 @@ class Detector:
         return ms[:max(k, 0)]
 
     def counters(self):
-        out = np.zeros(12, np.int64)
-        k = self._lib.ocvar_hip_counters(self._ctx, _ptr(out), 12)
+        out = np.zeros(10, np.int64)
+        k = self._lib.ocvar_hip_counters(self._ctx, _ptr(out), 10)
         return out[:max(k, 0)]

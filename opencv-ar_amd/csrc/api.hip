@@ -1,8 +1,9 @@
 // api.hip -- the thin C ABI of include/ocvar_hip.h: context, device workspace, launch sequence, result copy-out.
 //
-// One batch = 7 kernel launches on one HIP stream, no host round trip in between (work counts stay in
+// One batch = 11 kernel launches on one HIP stream, no host round trip in between (work counts stay in
 // device memory and the second-pass kernels are launched with fixed grids that read them):
-//   binarise(frames) -> follow(frames) -> order+crops -> binarise(crops) -> follow(crops) -> decode -> finalise
+//   binarise(frames) -> follower tiers 1,2,3 (frames) -> order+crops -> binarise(crops) -> follower tiers 1,2,3 (crops)
+//   -> decode -> finalise
 // There is deliberately no CPU path here: if the device or the code object is missing, create() fails.
 #include "kernels.h"
 #include <cstdio>
@@ -27,6 +28,8 @@ struct OcvarHip {
     std::vector<void*> allocs;
     uint8_t* d_frames = nullptr;  // staging for the host-buffer entry points
     size_t d_frames_bytes = 0;
+    uint8_t* h_stage = nullptr;   // page-locked bounce buffer of the small-call path of ocvar_hip_detect_host
+    size_t h_stage_bytes = 0;
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;   // host transport of ocvar_hip_detect_host (created on first use)
     std::vector<hipEvent_t> h2d_done;
     hipEvent_t computed = nullptr;
@@ -142,6 +145,7 @@ extern "C" void ocvar_hip_destroy(OcvarHip* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->d_frames) (void)hipFree(c->d_frames);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_markers) (void)hipHostFree(c->h_markers);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -213,7 +217,10 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     if (w.mid_blocks < 1 || w.mid_blocks > w.max_mid_blocks) w.mid_blocks = w.max_mid_blocks;
     w.long_blocks = std::getenv("OCVAR_LONG_BLOCKS") ? std::atoi(std::getenv("OCVAR_LONG_BLOCKS")) : w.max_long_blocks;
     if (w.long_blocks < 1 || w.long_blocks > w.max_long_blocks) w.long_blocks = w.max_long_blocks;
-    w.dbg = std::getenv("OCVAR_DBG") ? std::atoi(std::getenv("OCVAR_DBG")) : 0;
+    // the fixed grids of the work-queue kernels shrink with the batch: a one-frame call does not launch (and wait out) the
+    // thousands of workgroups that keep a 2048-frame batch busy
+    w.short_blocks = n_frames >= 128 ? 1024 : (n_frames * 8 < 16 ? 16 : n_frames * 8);
+    w.crop_blocks = n_frames >= 128 ? 2048 : (n_frames * 16 < 32 ? 32 : n_frames * 16);
     w.frame_strips = (w.sw + MARCH_STRIP - 1) / MARCH_STRIP;
     {   // rows per binarise work unit: even, chunks of equal size.  Every chunk re-reads ~12 halo rows, so chunks are as
         // tall as the batch allows while the launch still has >= 64K waves (env OCVAR_MIN_UNITS); never < ~128 rows.  (Measured: choosing the
@@ -390,17 +397,30 @@ extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int
         else if (e == hipErrorHostMemoryAlreadyRegistered) pinned = true;
         (void)hipGetLastError();
     }
-    if (!pinned) {   // one frame, or a buffer that cannot be page-locked: synchronous copies, sub-batch by sub-batch
+    if (!pinned) {
+        // One frame (the reference's per-frame call, ARTest.cpp:57), or a buffer that cannot be page-locked: the frames go
+        // through the context's own page-locked bounce buffer, so both transfers are plain stream-ordered DMA (a pageable
+        // hipMemcpy is staged by the runtime chunk by chunk and blocks twice).
         const int sub = c->ws.max_batch;
         for (int k = 0; k * sub < n_frames; k++) {
             const int cnt = (k + 1) * sub <= n_frames ? sub : n_frames - k * sub;
             const size_t off = (size_t)k * sub * frame_stride, len = (size_t)(cnt - 1) * frame_stride + frame_bytes;
-            HIP_TRY(c, hipMemcpy(c->d_frames + off, h_bgr + off, len, hipMemcpyHostToDevice));
-            rc = ocvar_hip_detect_device(c, c->d_frames + off, width, height, row_stride, frame_stride, cnt, grey_in_place,
-                                         prev ? prev + (size_t)k * sub * MAXM : nullptr, prev_counts ? prev_counts + k * sub : nullptr,
-                                         markers ? markers + (size_t)k * sub * max_per_frame : nullptr, counts + k * sub, max_per_frame);
+            if (len > c->h_stage_bytes) {
+                if (c->h_stage) (void)hipHostFree(c->h_stage);
+                c->h_stage = nullptr;
+                c->h_stage_bytes = 0;
+                HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, len));
+                c->h_stage_bytes = len;
+            }
+            std::memcpy(c->h_stage, h_bgr + off, len);
+            HIP_TRY(c, hipMemcpyAsync(c->d_frames + off, c->h_stage, len, hipMemcpyHostToDevice, c->stream));
+            rc = enqueue_impl(c, c->d_frames + off, width, height, row_stride, frame_stride, cnt, grey_in_place,
+                              prev ? prev + (size_t)k * sub * MAXM : nullptr, prev_counts ? prev_counts + k * sub : nullptr, c->stream, 3);
             if (rc) return rc;
-            if (grey_in_place) HIP_TRY(c, hipMemcpy(h_bgr + off, c->d_frames + off, len, hipMemcpyDeviceToHost));
+            if (grey_in_place) HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_frames + off, len, hipMemcpyDeviceToHost, c->stream));
+            rc = ocvar_hip_collect(c, markers ? markers + (size_t)k * sub * max_per_frame : nullptr, counts + k * sub, max_per_frame);
+            if (rc) return rc;
+            if (grey_in_place) std::memcpy(h_bgr + off, c->h_stage, len);
         }
         return OCVAR_OK;
     }
@@ -584,11 +604,11 @@ extern "C" int ocvar_hip_debug_calibrate(OcvarHip* c, size_t bytes) {
 extern "C" int ocvar_hip_counters(OcvarHip* c, long long* out, int n) {
     if (!c || !out || n < 1 || c->pending) return OCVAR_E_ARG;
     const int* h = c->h_counters;
-    long long v[12] = {h[CNT_FRAME_CANDS], h[CNT_CROP_ROIS], h[CNT_CROP_TILES], h[CNT_CROP_CANDS],
+    long long v[10] = {h[CNT_FRAME_CANDS], h[CNT_CROP_ROIS], h[CNT_CROP_TILES], h[CNT_CROP_CANDS],
                       (long long)*reinterpret_cast<const unsigned long long*>(h + CNT_CROP_PIXELS),
                       (long long)*reinterpret_cast<const unsigned long long*>(h + CNT_POOL_INTS),
-                      h[CNT_MID_F], h[CNT_MID_C], h[CNT_LONG_F], h[CNT_LONG_C], h[22], h[23]};
+                      h[CNT_MID_F], h[CNT_MID_C], h[CNT_LONG_F], h[CNT_LONG_C]};
     int k = 0;
-    for (; k < 12 && k < n; k++) out[k] = v[k];
+    for (; k < 10 && k < n; k++) out[k] = v[k];
     return k;
 }

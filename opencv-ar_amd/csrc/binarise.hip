@@ -476,7 +476,13 @@ __global__ __launch_bounds__(256) void binarise_crops_kernel(Workspace ws) {
     // crop units differ in size (rows, and the follow-up of their start lists): waves pull them from a ticket counter.
     // (The ticket test uses an opaque copy of the lane id: see follow.hip::ticket_lane for the compiler hazard.)
     int* ticket = ws.counters + CNT_TICKET_BC;
-    for (;;) {
+    // a wave can be handed at most n_units tickets (+ the one that tells it to stop): anything beyond that means the loop's
+    // control flow is broken; report instead of spinning
+    for (int guard = n_units + 1;; guard--) {
+        if (guard < 0) {
+            if ((threadIdx.x & 63) == 0) atomicOr(ws.counters + CNT_ERR, ERR_TICKET_RUNAWAY);
+            break;
+        }
         int lane_id = (int)(threadIdx.x & 63);
         asm volatile("" : "+v"(lane_id));
         int u = 0;
@@ -514,7 +520,7 @@ void launch_binarise_frames(const Workspace& ws, const uint8_t* d_bgr, int row_s
 }
 
 void launch_binarise_crops(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(binarise_crops_kernel, dim3(2048), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL(binarise_crops_kernel, dim3(ws.crop_blocks), dim3(256), 0, stream, ws);
 }
 
 }  // namespace ocvar

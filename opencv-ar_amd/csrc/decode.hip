@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
     __shared__ int s_tid[MAXC];
     __shared__ unsigned char s_score[MAXC];
     __shared__ int s_src[MAXM];  // >= 0: candidate index, < 0: -(1 + index into prev)
-    __shared__ int s_nout, s_total;
+    __shared__ int s_nout;
     const int f = blockIdx.x;
     const int T = ws.n_templates;
     if (threadIdx.x == 0) {
@@ -98,7 +98,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
                 total++;
             }
         s_nout = nout;
-        s_total = total;
+        // more markers than a frame's output block holds (tracking keeps duplicates, opencvar.cpp:662-668): the next frame's
+        // `prev` would be cut short and its tracking would diverge from the reference -- fail loudly instead
+        if (total > MAXM) atomicOr(ws.counters + CNT_ERR, ERR_MARKER_OVERFLOW);
         ws.n_markers[f] = total;
     }
     __syncthreads();

@@ -439,7 +439,13 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
     __shared__ StartCand wqueue[TIER == 1 ? 4 : 1][TIER == 1 ? 128 : 1];
     int queued = 0;      // wave-uniform
     bool more = true;    // tickets left
-    for (;;) {
+    // every iteration consumes a ticket of 64 starts or up to 64 queued survivors: more iterations than that account for
+    // means the loop's control flow is broken (see ticket_lane()); report instead of spinning
+    for (int guard = 2 * (n / 64 + 2) + 2;; guard--) {
+        if (guard < 0) {
+            if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TICKET_RUNAWAY);
+            break;
+        }
         StartCand c;
         c.roi = 0; c.pos = 0; c.is_hole = 0;
         int route = 0, slab_npts = 0;
@@ -628,7 +634,7 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
             const int nl = __builtin_amdgcn_readlane(slab_npts, L);
             const unsigned* sl = wave_slabs + (size_t)L * SLAB_STRIDE;
             const PlaneRef pll = plane_of<CROP>(ws, cl.roi);
-            if (!(ws.dbg & 1)) wave_finish_packed<CROP, true>(ws, cl, pll, sl, nl, parked[wave], &scratch[wave]);
+            wave_finish_packed<CROP, true>(ws, cl, pll, sl, nl, parked[wave], &scratch[wave]);
         }
         // budget exhausted: queue for the wave tier
         const unsigned long long mask = __ballot(route == 1);
@@ -959,10 +965,10 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
 }
 
 void launch_follow_frames(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL((follow_kernel<false, 1>), dim3(1024), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL((follow_kernel<false, 1>), dim3(ws.short_blocks), dim3(256), 0, stream, ws);
 }
 void launch_follow_crops(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL((follow_kernel<true, 1>), dim3(1024), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL((follow_kernel<true, 1>), dim3(ws.short_blocks), dim3(256), 0, stream, ws);
 }
 void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_mid_kernel<false>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws);

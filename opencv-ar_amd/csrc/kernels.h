@@ -56,8 +56,8 @@ struct Workspace {
     // per batch geometry
     int W, H, sw, sh, ns, n_frames, n_templates;   // ns: row stride of a neighbour-mask plane = sw rounded up to 4
     int mid_steps, mid_blocks, long_blocks;  // tuning (env OCVAR_MID_STEPS / OCVAR_MID_BLOCKS / OCVAR_LONG_BLOCKS): tier-2 step budget and grid, tier-3 grid
-    int dbg;  // TEMP diagnostics
     int max_mid_blocks, max_long_blocks;     // slabs allocated at create (scaled with max_batch)
+    int short_blocks, crop_blocks;           // grids of follower tier 1 and of the crop binarise kernel (scaled with the batch)
     int frame_strips, frame_chunks, frame_chunk_rows;  // binarise work decomposition of a frame
     // device buffers
     uint8_t* gray;          // [B][H][W]

@@ -1,0 +1,212 @@
+// multi_gpu.cpp -- include/ocvar_multi.h: one process, N GPUs, frames sharded by index, one RCCL gather per batch.
+//
+// Reference side: the per-frame caller loop of /root/reference/samples/ARTest.cpp:43-82 (one cvarArMultRegistration per
+// frame); frames are independent in stateless mode, so they are the shards.  Built as its own library
+// (lib/libocvar_multi.so, links librccl) so that the single-GPU library carries no RCCL dependency.
+#include "ocvar_multi.h"
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct OcvarMulti {
+    int n = 0, max_local = 0;
+    std::vector<int> dev;
+    std::vector<OcvarHip*> ctx;
+    std::vector<ncclComm_t> comm;
+    std::vector<hipStream_t> stream;
+    std::vector<uint8_t*> d_block;    // per device: [max_local] x MAXM markers, then [max_local] counts
+    std::vector<uint8_t*> d_frames;   // per device: staging of ocvar_multi_detect_host
+    size_t d_frames_bytes = 0;
+    uint8_t* d_all = nullptr;         // root: n blocks
+    uint8_t* h_all = nullptr;         // pinned
+    size_t block_bytes = 0;
+    std::string err;
+};
+
+namespace {
+constexpr int MAXM = OCVAR_MAX_MARKERS;
+size_t marker_bytes(int frames) { return (size_t)frames * MAXM * sizeof(OcvarMarker); }
+
+#define M_HIP(m, call)                                                              \
+    do {                                                                            \
+        hipError_t e_ = (call);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            (m)->err = std::string(#call) + ": " + hipGetErrorString(e_);          \
+            return OCVAR_E_HIP;                                                     \
+        }                                                                           \
+    } while (0)
+#define M_NCCL(m, call)                                                             \
+    do {                                                                            \
+        ncclResult_t r_ = (call);                                                   \
+        if (r_ != ncclSuccess) {                                                    \
+            (m)->err = std::string(#call) + ": " + ncclGetErrorString(r_);         \
+            return OCVAR_E_RCCL;                                                    \
+        }                                                                           \
+    } while (0)
+}  // namespace
+
+extern "C" int ocvar_multi_create(OcvarMulti** out, const int* devices, int n_devices, int max_width, int max_height, int max_frames_per_device) {
+    if (!out || n_devices < 1 || max_frames_per_device < 1) return OCVAR_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < n_devices) return OCVAR_E_NO_DEVICE;
+    OcvarMulti* m = new OcvarMulti();
+    *out = m;   // returned even on failure so the caller can read the error text, then destroy
+    m->n = n_devices;
+    m->max_local = max_frames_per_device;
+    for (int d = 0; d < n_devices; d++) m->dev.push_back(devices ? devices[d] : d);
+    m->block_bytes = marker_bytes(max_frames_per_device) + (size_t)max_frames_per_device * sizeof(int);
+    m->ctx.assign(n_devices, nullptr);
+    m->stream.assign(n_devices, nullptr);
+    m->d_block.assign(n_devices, nullptr);
+    m->d_frames.assign(n_devices, nullptr);
+    for (int d = 0; d < n_devices; d++) {
+        const int rc = ocvar_hip_create(&m->ctx[d], m->dev[d], max_width, max_height, max_frames_per_device);
+        if (rc != OCVAR_OK) {
+            m->err = std::string("ocvar_hip_create on device ") + std::to_string(m->dev[d]) + ": " +
+                     (m->ctx[d] ? ocvar_hip_last_error(m->ctx[d]) : "no gfx950 device");
+            return rc;
+        }
+        M_HIP(m, hipSetDevice(m->dev[d]));
+        M_HIP(m, hipStreamCreateWithFlags(&m->stream[d], hipStreamNonBlocking));
+        M_HIP(m, hipMalloc((void**)&m->d_block[d], m->block_bytes));
+    }
+    M_HIP(m, hipSetDevice(m->dev[0]));
+    M_HIP(m, hipMalloc((void**)&m->d_all, m->block_bytes * n_devices));
+    M_HIP(m, hipHostMalloc((void**)&m->h_all, m->block_bytes * n_devices));
+    m->comm.assign(n_devices, nullptr);
+    M_NCCL(m, ncclCommInitAll(m->comm.data(), n_devices, m->dev.data()));
+    return OCVAR_OK;
+}
+
+extern "C" void ocvar_multi_destroy(OcvarMulti* m) {
+    if (!m) return;
+    for (size_t d = 0; d < m->comm.size(); d++)
+        if (m->comm[d]) (void)ncclCommDestroy(m->comm[d]);
+    for (int d = 0; d < (int)m->ctx.size(); d++) {
+        (void)hipSetDevice(m->dev[d]);
+        if (m->stream[d]) {
+            (void)hipStreamSynchronize(m->stream[d]);
+            (void)hipStreamDestroy(m->stream[d]);
+        }
+        if (m->d_block[d]) (void)hipFree(m->d_block[d]);
+        if (m->d_frames[d]) (void)hipFree(m->d_frames[d]);
+        if (m->ctx[d]) ocvar_hip_destroy(m->ctx[d]);
+    }
+    if (!m->dev.empty()) (void)hipSetDevice(m->dev[0]);
+    if (m->d_all) (void)hipFree(m->d_all);
+    if (m->h_all) (void)hipHostFree(m->h_all);
+    delete m;
+}
+
+extern "C" const char* ocvar_multi_last_error(const OcvarMulti* m) { return m ? m->err.c_str() : "null context"; }
+extern "C" int ocvar_multi_devices(const OcvarMulti* m) { return m ? m->n : 0; }
+
+extern "C" int ocvar_multi_set_templates(OcvarMulti* m, const OcvarTemplate* t, int n) {
+    if (!m) return OCVAR_E_ARG;
+    for (int d = 0; d < m->n; d++) {
+        const int rc = ocvar_hip_set_templates(m->ctx[d], t, n);
+        if (rc) { m->err = ocvar_hip_last_error(m->ctx[d]); return rc; }
+    }
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_multi_set_camera(OcvarMulti* m, const OcvarCamera* cam) {
+    if (!m) return OCVAR_E_ARG;
+    for (int d = 0; d < m->n; d++) {
+        const int rc = ocvar_hip_set_camera(m->ctx[d], cam);
+        if (rc) { m->err = ocvar_hip_last_error(m->ctx[d]); return rc; }
+    }
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_multi_detect_device(OcvarMulti* m, uint8_t* const* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                         const int* n_local, OcvarMarker* markers, int* counts, int max_per_frame) {
+    if (!m || !d_bgr || !n_local || !counts || max_per_frame < 0 || (max_per_frame > 0 && !markers)) return OCVAR_E_ARG;
+    const int N = m->n;
+    for (int d = 0; d < N; d++)
+        if (n_local[d] < 0 || n_local[d] > m->max_local || (n_local[d] > 0 && !d_bgr[d])) return OCVAR_E_ARG;
+    // every device: detect its share (all kernels of the single-GPU path on the device's own stream), then put the result
+    // block into the send buffer behind them
+    for (int d = 0; d < N; d++) {
+        if (n_local[d] == 0) continue;
+        M_HIP(m, hipSetDevice(m->dev[d]));
+        int rc = ocvar_hip_enqueue(m->ctx[d], d_bgr[d], width, height, row_stride, frame_stride, n_local[d], 0, nullptr, nullptr, m->stream[d]);
+        if (rc) { m->err = ocvar_hip_last_error(m->ctx[d]); return rc; }
+        rc = ocvar_hip_results_to_device(m->ctx[d], reinterpret_cast<OcvarMarker*>(m->d_block[d]),
+                                         reinterpret_cast<int*>(m->d_block[d] + marker_bytes(m->max_local)), m->stream[d]);
+        if (rc) { m->err = ocvar_hip_last_error(m->ctx[d]); return rc; }
+    }
+    // one gather of the fixed-size blocks to the root (device 0 of the list); a single-thread caller issues all ranks'
+    // calls inside one group
+    M_NCCL(m, ncclGroupStart());
+    for (int d = 0; d < N; d++) {
+        const ncclResult_t r = ncclGather(m->d_block[d], d == 0 ? m->d_all : nullptr, m->block_bytes, ncclUint8, 0, m->comm[d], m->stream[d]);
+        if (r != ncclSuccess) {
+            (void)ncclGroupEnd();
+            m->err = std::string("ncclGather: ") + ncclGetErrorString(r);
+            return OCVAR_E_RCCL;
+        }
+    }
+    M_NCCL(m, ncclGroupEnd());
+    M_HIP(m, hipSetDevice(m->dev[0]));
+    M_HIP(m, hipMemcpyAsync(m->h_all, m->d_all, m->block_bytes * N, hipMemcpyDeviceToHost, m->stream[0]));
+    // collect per device (reports capacity errors of that device's batch), root last: its stream carries the copy-out
+    int first_err = OCVAR_OK;
+    std::vector<int> scratch_counts((size_t)m->max_local);
+    for (int d = N - 1; d >= 0; d--) {
+        if (n_local[d] == 0) continue;
+        M_HIP(m, hipSetDevice(m->dev[d]));
+        const int rc = ocvar_hip_collect(m->ctx[d], nullptr, scratch_counts.data(), 0);
+        if (rc && !first_err) {
+            first_err = rc;
+            m->err = std::string("device ") + std::to_string(m->dev[d]) + ": " + ocvar_hip_last_error(m->ctx[d]);
+        }
+    }
+    M_HIP(m, hipSetDevice(m->dev[0]));
+    M_HIP(m, hipStreamSynchronize(m->stream[0]));
+    if (first_err) return first_err;
+    // root: blocks in rank order -> caller order (global frame d + N*i)
+    for (int d = 0; d < N; d++) {
+        const uint8_t* blk = m->h_all + (size_t)d * m->block_bytes;
+        const OcvarMarker* mk = reinterpret_cast<const OcvarMarker*>(blk);
+        const int* cn = reinterpret_cast<const int*>(blk + marker_bytes(m->max_local));
+        for (int i = 0; i < n_local[d]; i++) {
+            const size_t g = (size_t)d + (size_t)N * i;
+            counts[g] = cn[i];
+            int k = cn[i] < max_per_frame ? cn[i] : max_per_frame;
+            if (k > MAXM) k = MAXM;
+            if (k > 0) std::memcpy(markers + g * max_per_frame, mk + (size_t)i * MAXM, (size_t)k * sizeof(OcvarMarker));
+        }
+    }
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_multi_detect_host(OcvarMulti* m, const uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                       int n_frames, OcvarMarker* markers, int* counts, int max_per_frame) {
+    if (!m || !h_bgr || n_frames < 1 || n_frames > m->n * m->max_local || height < 1 || row_stride < 3 * width) return OCVAR_E_ARG;
+    if (n_frames > 1 && frame_stride < (size_t)height * row_stride) return OCVAR_E_ARG;
+    const int N = m->n;
+    const size_t fb = (size_t)height * row_stride;
+    std::vector<int> n_local(N, 0);
+    for (int f = 0; f < n_frames; f++) n_local[f % N]++;
+    if (fb * m->max_local > m->d_frames_bytes) {
+        for (int d = 0; d < N; d++) {
+            M_HIP(m, hipSetDevice(m->dev[d]));
+            if (m->d_frames[d]) (void)hipFree(m->d_frames[d]);
+            m->d_frames[d] = nullptr;
+            M_HIP(m, hipMalloc((void**)&m->d_frames[d], fb * m->max_local));
+        }
+        m->d_frames_bytes = fb * m->max_local;
+    }
+    // frame f -> device f mod N, local slot f / N; copies ordered before the detection on the device's stream
+    for (int f = 0; f < n_frames; f++) {
+        const int d = f % N;
+        M_HIP(m, hipSetDevice(m->dev[d]));
+        M_HIP(m, hipMemcpyAsync(m->d_frames[d] + (size_t)(f / N) * fb, h_bgr + (size_t)f * frame_stride, fb, hipMemcpyHostToDevice, m->stream[d]));
+    }
+    return ocvar_multi_detect_device(m, m->d_frames.data(), width, height, row_stride, fb, n_local.data(), markers, counts, max_per_frame);
+}

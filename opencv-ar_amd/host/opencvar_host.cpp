@@ -4,8 +4,8 @@
 // MI355X; everything else here is setup-side or tiny per-quad host arithmetic.
 //
 // Deliberate differences: no exception ever crosses the C boundary (failures return
-// 0 / an empty result and print one line to stderr); the reference's leaks (D12) are not reproduced; the camera
-// YAML reader and anti-aliased drawing are not provided (out of scope).
+// 0 / an empty result and print one line to stderr); the reference's leaks (D12) are not reproduced;
+// cvarDrawSquares draws aliased 1-px lines instead of anti-aliased ones (display aid).
 #include "opencvar/opencvar.h"
 #include "opencvar/acmath.h"
 #include "ocvar_hip.h"
@@ -15,6 +15,7 @@
 
 #include <zlib.h>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,24 +28,58 @@ static_assert(sizeof(CvarCamera) == sizeof(OcvarCamera) && sizeof(CvarCamera) ==
 static_assert(sizeof(CvarTemplate) == sizeof(OcvarTemplate) && sizeof(CvarTemplate) == 48, "CvarTemplate layout");
 static_assert(sizeof(CvarMarker) == sizeof(OcvarMarker) && sizeof(CvarMarker) == 184, "CvarMarker layout");
 
-// The sequence cvarFindSquares hands out.  With real OpenCV headers CvSeq is OpenCV's own type and these
-// debug-side functions would need cvCreateSeq; in this build (stand-in headers) the type is ours.
-struct CvSeq {
-    int total;  // number of CvPoint elements (4 per square), as the reference's callers read it
-    std::vector<CvPoint> elems;
-};
+static_assert(offsetof(CvSeq, total) == 40 && offsetof(CvSeq, elem_size) == 44 && offsetof(CvSeq, first) == 88 && sizeof(CvSeq) == 96,
+              "CvSeq layout of OpenCV 2.x/3.x (types_c.h)");
 
 namespace {
+
+// The sequence cvarFindSquares hands out: a CvSeq header with OpenCV's layout over one element block owned by this
+// library (the reference allocates it in the caller's CvMemStorage; a caller only reads it, through `total`, cvGetSeqElem
+// or the cvarGet* accessors below).  Only public CvSeq fields are used, so this compiles against real OpenCV headers too.
+struct OwnedSeq {
+    CvSeq seq;
+    CvSeqBlock block;
+    std::vector<CvPoint> pts;
+    void seal() {
+        std::memset(&seq, 0, sizeof seq);
+        std::memset(&block, 0, sizeof block);
+        seq.flags = 0x42990000 | 12;   // CV_SEQ_MAGIC_VAL | CV_SEQ_ELTYPE_POINT (CV_32SC2)
+        seq.header_size = (int)sizeof(CvSeq);
+        seq.total = (int)pts.size();
+        seq.elem_size = (int)sizeof(CvPoint);
+        block.prev = block.next = &block;
+        block.count = seq.total;
+        block.data = reinterpret_cast<signed char*>(pts.data());
+        seq.first = pts.empty() ? nullptr : &block;
+        seq.block_max = seq.ptr = block.data + sizeof(CvPoint) * pts.size();
+    }
+};
+
+// element i of a point sequence, walking the blocks as cvGetSeqElem does (works on OpenCV-made sequences as well)
+const CvPoint* seq_point(const CvSeq* seq, int i) {
+    const CvSeqBlock* b = seq->first;
+    while (b && i >= b->count) {
+        i -= b->count;
+        b = b->next;
+        if (b == seq->first) return nullptr;
+    }
+    return b ? reinterpret_cast<const CvPoint*>(b->data + (size_t)i * seq->elem_size) : nullptr;
+}
 
 std::mutex g_mu;
 OcvarHip* g_ctx = nullptr;
 int g_w = 0, g_h = 0;
-std::deque<std::unique_ptr<CvSeq>> g_seqs;  // keeps returned sequences alive (the reference uses CvMemStorage)
+std::deque<std::unique_ptr<OwnedSeq>> g_seqs;  // keeps returned sequences alive (the reference uses CvMemStorage)
+std::vector<CvarTemplate> g_templates;        // what the context currently holds: unchanged arguments are not uploaded again
+CvarCamera g_camera;
+bool g_have_camera = false;
 
 OcvarHip* context_for(int w, int h) {
     if (g_ctx && w <= g_w && h <= g_h) return g_ctx;
     if (g_ctx) ocvar_hip_destroy(g_ctx);
     g_ctx = nullptr;
+    g_templates.clear();
+    g_have_camera = false;
     const int dev = std::getenv("OCVAR_DEVICE") ? std::atoi(std::getenv("OCVAR_DEVICE")) : 0;
     int rc = ocvar_hip_create(&g_ctx, dev, w < 64 ? 64 : w, h < 64 ? 64 : h, 1);
     if (rc != OCVAR_OK) {
@@ -291,9 +326,18 @@ void cvarSquareToMatrix(CvPoint2D32f* points, CvarCamera* cam, double* modelview
 }
 
 void cvarFindCamera(CvarCamera* cam, CvMat* objPts, CvMat* imgPts, double* modelview) {
-    // The reference passes arbitrary object points; this library's solver is the marker rectangle
-    // (+-ratio, +-1, 0) that cvarSquareInit produces -- the only use in the reference (opencvar.cpp:529-536).
-    const double ratio = std::fabs(objPts->data.db[0]);
+    // The reference hands arbitrary object points to cvFindExtrinsicCameraParams2; this library's solver is the planar
+    // one for the marker rectangle (+-ratio, +-1, 0) that cvarSquareInit produces -- the only use in the reference
+    // (opencvar.cpp:529-536).  Anything else is refused loudly instead of being solved as if it were that rectangle.
+    if (!cam || !objPts || !imgPts || !modelview || !objPts->data.db || !imgPts->data.db) return;
+    const double* o = objPts->data.db;
+    const double ratio = std::fabs(o[0]);
+    const double want[12] = {-ratio, -1, 0, ratio, -1, 0, ratio, 1, 0, -ratio, 1, 0};
+    for (int i = 0; i < 12; i++)
+        if (o[i] != want[i]) {
+            std::fprintf(stderr, "opencvar: cvarFindCamera: object points are not the marker rectangle of cvarSquareInit; not solved\n");
+            return;
+        }
     CvPoint2D32f p[4];
     for (int i = 0; i < 4; i++) {
         p[i].x = (float)imgPts->data.db[2 * i];
@@ -354,37 +398,54 @@ int cvarTrack(CvPoint2D32f pt1[4], CvPoint2D32f pt2[4]) { return ocvar::track_sq
 
 CvSeq* cvarFindSquares(IplImage* img, CvMemStorage* /*storage*/) {
     std::lock_guard<std::mutex> lk(g_mu);
-    std::unique_ptr<CvSeq> seq(new CvSeq{0, {}});
+    std::unique_ptr<OwnedSeq> seq(new OwnedSeq());
     if (image_ok(img)) {
         OcvarHip* ctx = context_for(img->width, img->height);
         if (ctx) {
-            // the reference runs on a 3-channel image whose channels are equal after the in-place grey; take B
+            // The hot path calls this on images whose three channels are equal (after the in-place grey), where the grey
+            // value is the channel value.  A colour image is greyed with the BGR2GRAY weights first; the reference filters
+            // the three channels separately and greys afterwards (opencvar.cpp:175-180), which can differ by rounding --
+            // said once on stderr.
             std::vector<unsigned char> gray((size_t)img->width * img->height);
-            for (int y = 0; y < img->height; y++)
-                for (int x = 0; x < img->width; x++)
-                    gray[(size_t)y * img->width + x] = (unsigned char)img->imageData[(size_t)y * img->widthStep + 3 * x];
-            std::vector<int> quads(OCVAR_MAX_QUADS * 8);
+            bool colour = false;
+            for (int y = 0; y < img->height; y++) {
+                const unsigned char* row = (const unsigned char*)img->imageData + (size_t)y * img->widthStep;
+                for (int x = 0; x < img->width; x++) {
+                    const unsigned b = row[3 * x], g = row[3 * x + 1], r = row[3 * x + 2];
+                    colour |= b != g || g != r;
+                    gray[(size_t)y * img->width + x] = (unsigned char)((b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14);
+                }
+            }
+            static bool told = false;
+            if (colour && !told) {
+                told = true;
+                std::fprintf(stderr, "opencvar: cvarFindSquares: colour image greyed before the pyramid filter (the reference filters per channel)\n");
+            }
+            // (more than OCVAR_MAX_QUADS squares in one image: the call fails with OCVAR_E_CAPACITY, reported below)
+            std::vector<int> quads((size_t)OCVAR_MAX_QUADS * 8);
             int n = 0;
-            if (ocvar_hip_find_squares(ctx, gray.data(), img->width, img->height, img->width, quads.data(), OCVAR_MAX_QUADS, &n) == OCVAR_OK) {
-                if (n > OCVAR_MAX_QUADS) n = OCVAR_MAX_QUADS;
-                for (int i = 0; i < 4 * n; i++) seq->elems.push_back(CvPoint{quads[2 * i], quads[2 * i + 1]});
-                seq->total = 4 * n;
+            const int rc = ocvar_hip_find_squares(ctx, gray.data(), img->width, img->height, img->width, quads.data(), OCVAR_MAX_QUADS, &n);
+            if (rc == OCVAR_OK) {
+                for (int i = 0; i < 4 * n; i++) seq->pts.push_back(CvPoint{quads[2 * i], quads[2 * i + 1]});
             } else {
                 std::fprintf(stderr, "opencvar: cvarFindSquares failed: %s\n", ocvar_hip_last_error(ctx));
             }
         }
     }
+    seq->seal();
     g_seqs.push_back(std::move(seq));
     if (g_seqs.size() > 256) g_seqs.pop_front();
-    return g_seqs.back().get();
+    return &g_seqs.back()->seq;
 }
 
 int cvarGetSquare(CvSeq* squares, CvPoint2D32f* points) {
     int res = 0;
     for (int i = 0; squares && i + 3 < squares->total; i += 4, res++)
         for (int j = 0; j < 4; j++) {
-            points[j].x = (float)squares->elems[i + j].x;
-            points[j].y = (float)squares->elems[i + j].y;
+            const CvPoint* p = seq_point(squares, i + j);
+            if (!p) return res;
+            points[j].x = (float)p->x;
+            points[j].y = (float)p->y;
         }
     return res;
 }
@@ -392,7 +453,11 @@ int cvarGetSquare(CvSeq* squares, CvPoint2D32f* points) {
 int cvarGetAllSquares(CvSeq* squares, vector<CvPoint2D32f>* pts) {
     int res = 0;
     for (int i = 0; squares && i + 3 < squares->total; i += 4, res++)
-        for (int j = 0; j < 4; j++) pts->push_back(CvPoint2D32f{(float)squares->elems[i + j].x, (float)squares->elems[i + j].y});
+        for (int j = 0; j < 4; j++) {
+            const CvPoint* p = seq_point(squares, i + j);
+            if (!p) return res;
+            pts->push_back(CvPoint2D32f{(float)p->x, (float)p->y});
+        }
     return res;
 }
 
@@ -402,7 +467,8 @@ int cvarCompareSquare(IplImage* img, CvPoint2D32f* points) {
     for (int i = 0; i + 3 < sq->total; i += 4)
         for (int j = 0; j < 4; j++)
             for (int k = 0; k < 4; k++) {
-                const double dx = points[j].x - sq->elems[i + k].x, dy = points[j].y - sq->elems[i + k].y;
+                const CvPoint* p = seq_point(sq, i + k);
+                const double dx = points[j].x - p->x, dy = points[j].y - p->y;
                 if (std::sqrt(dx * dx + dy * dy) < 10) match++;
             }
     return match;
@@ -414,7 +480,9 @@ int cvarDrawSquares(IplImage* img, CvSeq* squares) {
     if (!image_ok(img) || !squares) return 0;
     for (int i = 0; i + 3 < squares->total; i += 4, res++)
         for (int e = 0; e < 4; e++) {
-            CvPoint a = squares->elems[i + e], b = squares->elems[i + ((e + 1) & 3)];
+            const CvPoint *pa = seq_point(squares, i + e), *pb = seq_point(squares, i + ((e + 1) & 3));
+            if (!pa || !pb) return res;
+            const CvPoint a = *pa, b = *pb;
             const int steps = std::max(std::abs(b.x - a.x), std::abs(b.y - a.y));
             for (int s = 0; s <= steps; s++) {
                 const int x = a.x + (steps ? (int)std::lround((double)(b.x - a.x) * s / steps) : 0);
@@ -485,14 +553,30 @@ int cvarArMultRegistration(IplImage* image, vector<CvarMarker>* markers, vector<
         markers->clear();
         return 0;
     }
-    if (ocvar_hip_set_templates(ctx, reinterpret_cast<const OcvarTemplate*>(templates.data()), (int)templates.size()) != OCVAR_OK ||
-        ocvar_hip_set_camera(ctx, reinterpret_cast<const OcvarCamera*>(camera)) != OCVAR_OK) {
+    // templates and camera are uploaded only when they differ from what the context holds (a caller passes the same ones
+    // frame after frame, ARTest.cpp:57)
+    const bool same_t = g_templates.size() == templates.size() &&
+                        std::memcmp(g_templates.data(), templates.data(), templates.size() * sizeof(CvarTemplate)) == 0;
+    const bool same_c = g_have_camera && std::memcmp(&g_camera, camera, sizeof(CvarCamera)) == 0;
+    if ((!same_t && ocvar_hip_set_templates(ctx, reinterpret_cast<const OcvarTemplate*>(templates.data()), (int)templates.size()) != OCVAR_OK) ||
+        (!same_c && ocvar_hip_set_camera(ctx, reinterpret_cast<const OcvarCamera*>(camera)) != OCVAR_OK)) {
         std::fprintf(stderr, "opencvar: %s\n", ocvar_hip_last_error(ctx));
+        g_templates.clear();
+        g_have_camera = false;
+        markers->clear();
+        return 0;
+    }
+    g_templates = templates;
+    g_camera = *camera;
+    g_have_camera = true;
+    if (markers->size() > OCVAR_MAX_MARKERS) {
+        std::fprintf(stderr, "opencvar: cvarArMultRegistration: %zu markers carried in, this build tracks at most %d per frame\n",
+                     markers->size(), OCVAR_MAX_MARKERS);
         markers->clear();
         return 0;
     }
     std::vector<OcvarMarker> prev(OCVAR_MAX_MARKERS);
-    int n_prev = (int)std::min<size_t>(markers->size(), OCVAR_MAX_MARKERS);
+    int n_prev = (int)markers->size();
     if (n_prev) std::memcpy(prev.data(), markers->data(), n_prev * sizeof(OcvarMarker));
     std::vector<OcvarMarker> out(OCVAR_MAX_MARKERS);
     int count = 0;
@@ -504,8 +588,7 @@ int cvarArMultRegistration(IplImage* image, vector<CvarMarker>* markers, vector<
         std::fprintf(stderr, "opencvar: detection failed (%d): %s\n", rc, ocvar_hip_last_error(ctx));
         return 0;
     }
-    if (count > OCVAR_MAX_MARKERS) count = OCVAR_MAX_MARKERS;
-    markers->resize(count);
+    markers->resize(count);   // (more than OCVAR_MAX_MARKERS would have failed above with OCVAR_E_CAPACITY)
     if (count) std::memcpy(markers->data(), out.data(), count * sizeof(OcvarMarker));
     return (int)markers->size();
 }

@@ -21,7 +21,8 @@ def block_bytes(batch):
 def gather_blocks(local_block, rank, world, dist=None):
     """local_block: uint8 tensor [block_bytes(B)] on the rank's device.  Returns on rank 0 a list of `world`
     tensors (rank order), elsewhere None."""
-    if world == 1:
+    if dist is None or not dist.is_initialized():   # single process, no process group: nothing to exchange
+        assert world == 1
         return [local_block]
     if local_block.is_cuda and dist.get_backend() == "gloo":   # rehearsal of the N > 1 flow without RCCL: stage through the host
         local_block = local_block.cpu()

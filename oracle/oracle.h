@@ -28,6 +28,7 @@
 #ifndef ORC_ORACLE_H
 #define ORC_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -111,6 +112,12 @@ void orc_square_to_matrix(const float* pts8, const OrcCamera* cam, double ratio,
 int orc_registration(uint8_t* bgr, int w, int h, int stride, OrcMarker* markers, int n_in, int max_markers,
                      const OrcTemplate* templates, int n_templates, const OrcCamera* cam, OrcCandidate* cands,
                      int max_cands, int* n_cands);
+
+/* Measurement aid (bench.py cpu_baseline): orc_registration frame-parallel over `threads` host threads (<= 0: all hardware
+ * threads) for about budget_s seconds; returns the number of frames processed, *seconds the wall time. */
+long long orc_registration_throughput(const uint8_t* frames, int n_frames, int w, int h, int stride, size_t frame_stride,
+                                      const OrcTemplate* templates, int n_templates, const OrcCamera* cam, int threads,
+                                      double budget_s, long long max_calls, double* seconds, int* threads_used);
 
 #ifdef __cplusplus
 }

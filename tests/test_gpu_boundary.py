@@ -1,0 +1,181 @@
+"""GPU tests of the boundaries around the hot path: the reference's debug square API through lib/libopencv-ar.so
+(SURVEY 8(f)4), the per-call latency sample, the RCCL result gather through torch.distributed and through
+the one-process C helper of include/ocvar_multi.h."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import P
+
+pytestmark = pytest.mark.gpu
+
+LIB = os.path.join(H.PKG, "lib", "libopencv-ar.so.1.0.0")
+BIN = os.path.join(H.PKG, "bin")
+TEMPLATES = os.path.join(H.ROOT, "assets", "templates")
+
+
+class IplImage(C.Structure):   # OpenCV's layout (include/shim/opencv/cv.h): 144 bytes on LP64
+    _fields_ = [("nSize", C.c_int), ("ID", C.c_int), ("nChannels", C.c_int), ("alphaChannel", C.c_int), ("depth", C.c_int),
+                ("colorModel", C.c_char * 4), ("channelSeq", C.c_char * 4), ("dataOrder", C.c_int), ("origin", C.c_int),
+                ("align", C.c_int), ("width", C.c_int), ("height", C.c_int), ("roi", C.c_void_p), ("maskROI", C.c_void_p),
+                ("imageId", C.c_void_p), ("tileInfo", C.c_void_p), ("imageSize", C.c_int), ("imageData", C.c_void_p),
+                ("widthStep", C.c_int), ("BorderMode", C.c_int * 4), ("BorderConst", C.c_int * 4), ("imageDataOrigin", C.c_void_p)]
+
+
+class CvSeqBlock(C.Structure):
+    pass
+
+
+CvSeqBlock._fields_ = [("prev", C.POINTER(CvSeqBlock)), ("next", C.POINTER(CvSeqBlock)), ("start_index", C.c_int),
+                       ("count", C.c_int), ("data", C.c_void_p)]
+
+
+class CvSeq(C.Structure):   # OpenCV 2.x/3.x CvSeq: total at offset 40
+    _fields_ = [("flags", C.c_int), ("header_size", C.c_int), ("h_prev", C.c_void_p), ("h_next", C.c_void_p), ("v_prev", C.c_void_p),
+                ("v_next", C.c_void_p), ("total", C.c_int), ("elem_size", C.c_int), ("block_max", C.c_void_p), ("ptr", C.c_void_p),
+                ("delta_elems", C.c_int), ("storage", C.c_void_p), ("free_blocks", C.c_void_p), ("first", C.POINTER(CvSeqBlock))]
+
+
+class StdVector(C.Structure):   # libstdc++ std::vector: begin, end, end of storage
+    _fields_ = [("begin", C.c_void_p), ("end", C.c_void_p), ("cap", C.c_void_p)]
+
+
+def ipl(bgr):
+    h, w = bgr.shape[:2]
+    img = IplImage()
+    img.nSize, img.nChannels, img.depth, img.width, img.height = C.sizeof(IplImage), 3, 8, w, h
+    img.widthStep, img.imageSize = bgr.strides[0], bgr.strides[0] * h
+    img.imageData = img.imageDataOrigin = bgr.ctypes.data
+    return img
+
+
+@pytest.fixture(scope="module")
+def host():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a device"
+    import opencv_ar_amd as oa
+    oa.hip_lib()
+    assert C.sizeof(IplImage) == 144 and CvSeq.total.offset == 40 and C.sizeof(CvSeq) == 96
+    lib = C.CDLL(LIB)
+    lib.cvarFindSquares.restype = C.POINTER(CvSeq)
+    lib.cvarFindSquares.argtypes = [C.c_void_p, C.c_void_p]
+    return lib
+
+
+def seq_points(seq):
+    """walks the element blocks the way cvGetSeqElem does"""
+    s = seq.contents
+    assert s.elem_size == 8 and s.header_size == 96
+    pts, blk = [], s.first
+    while len(pts) < s.total:
+        b = blk.contents
+        pts.extend(np.ctypeslib.as_array(C.cast(b.data, C.POINTER(C.c_int)), shape=(b.count, 2)).copy().tolist())
+        blk = b.next
+    return np.array(pts[:s.total], np.int32).reshape(-1, 4, 2)
+
+
+def test_debug_square_api_through_the_reference_boundary(host):
+    """cvarFindSquares -> cvarGetAllSquares / cvarGetSquare -> cvarCompareSquare -> cvarDrawSquares
+    (/root/reference/src/opencvar.cpp:156-223, 327-430, 564-590) on a greyed synthetic frame, against the oracle."""
+    cfg = H.synth_config(2)
+    frame, _ = H.synth_frame(cfg, 3, ["2x2-01"])
+    tpls, cam = H.oracle_templates(["2x2-01"]), H.oracle_camera(cfg.width, cfg.height)
+    _, _, grey = H.oracle_registration(frame, tpls, cam)   # the image the reference hands to cvarFindSquares (624-632)
+    ref = H.oracle_find_squares(np.ascontiguousarray(grey[..., 0]))
+    assert len(ref) >= 4
+    img_arr = np.ascontiguousarray(grey.copy())
+    img = ipl(img_arr)
+    seq = host.cvarFindSquares(C.byref(img), None)
+    assert seq.contents.total == 4 * len(ref)                # what a caller reads at OpenCV's offset of `total`
+    assert np.array_equal(seq_points(seq), ref)              # sequence order included
+    # cvarGetAllSquares appends CvPoint2D32f to the caller's vector (564-590)
+    vec = StdVector()
+    assert host.cvarGetAllSquares(seq, C.byref(vec)) == len(ref)
+    n_pts = (vec.end - vec.begin) // 8
+    got = np.ctypeslib.as_array(C.cast(vec.begin, C.POINTER(C.c_float)), shape=(n_pts, 2)).reshape(-1, 4, 2)
+    assert np.array_equal(got, ref.astype(np.float32))
+    # cvarGetSquare keeps the LAST square of the sequence (401-430)
+    last = np.zeros((4, 2), np.float32)
+    assert host.cvarGetSquare(seq, P(last)) == len(ref)
+    assert np.array_equal(last, ref[-1].astype(np.float32))
+    # cvarCompareSquare counts corner pairs closer than 10 px over every square of the image (327-367)
+    probe = ref[0].astype(np.float32)
+    want = sum(int(np.hypot(*(p - q.astype(np.float64))) < 10) for sq in ref for p in probe.astype(np.float64) for q in sq)
+    assert host.cvarCompareSquare(C.byref(img), P(probe)) == want
+    # cvarDrawSquares returns the number of squares and marks their corners green (369-399; aliased lines here)
+    assert host.cvarDrawSquares(C.byref(img), seq) == len(ref)
+    for sq in ref:
+        for x, y in sq:
+            assert img_arr[y, x].tolist() == [0, 255, 0]
+
+
+def test_find_squares_on_a_colour_image_uses_bgr2gray_weights(host):
+    cfg = H.synth_config(2)
+    frame, _ = H.synth_frame(cfg, 1, ["2x2-01"])
+    tinted = frame.copy()
+    tinted[..., 2] = (tinted[..., 2].astype(np.int32) * 3 // 4).astype(np.uint8)   # R != G = B
+    g = ((tinted[..., 0].astype(np.uint32) * 1868 + tinted[..., 1].astype(np.uint32) * 9617 + tinted[..., 2].astype(np.uint32) * 4899 + 8192) >> 14).astype(np.uint8)
+    ref = H.oracle_find_squares(np.ascontiguousarray(g))
+    img = ipl(tinted)
+    seq = host.cvarFindSquares(C.byref(img), None)
+    assert np.array_equal(seq_points(seq), ref)
+
+
+def test_per_call_latency_sample_runs():
+    out = subprocess.run([os.path.join(BIN, "artest_latency"), TEMPLATES, "2", "5"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["width"] == 640 and rec["markers_out"] >= 1 and 0 < rec["min_ms"] <= rec["median_ms"] <= rec["p90_ms"]
+
+
+def test_multi_gpu_helper_gathers_over_rccl():
+    """include/ocvar_multi.h on the devices of this box (one here): ncclCommInitAll + one ncclGather of the result block
+    per batch; the demo compares every CvarMarker record with the single-GPU entry point on the same frames."""
+    out = subprocess.run([os.path.join(BIN, "multi_gpu_demo"), TEMPLATES, "0", "2", "6", "2"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["devices"] >= 1 and rec["frames"] == 6 * rec["devices"] and rec["mismatches_vs_single_gpu"] == 0
+    assert rec["markers_total"] >= rec["frames"]
+
+
+def test_rccl_gather_of_result_blocks_world1():
+    """The bench's N > 1 exchange on real hardware: a torch.distributed process group with backend "nccl" (= RCCL), the
+    detector's device-resident result block pushed through sharding.gather_blocks and decoded with unpack."""
+    import torch
+    import torch.distributed as dist
+    import opencv_ar_amd as oa
+    from opencv_ar_amd import sharding as S
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg = H.synth_config(2)
+        n = 5
+        frames = np.stack([H.synth_frame(cfg, f, ["2x2-01"])[0] for f in range(n)])
+        tpls, cam = H.oracle_templates(["2x2-01"]), H.oracle_camera(cfg.width, cfg.height)
+        det = oa.Detector(cfg.width, cfg.height, max_batch=n)
+        det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls])
+        det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+        d = torch.from_numpy(frames).cuda()
+        block = torch.zeros(S.block_bytes(n), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        det.enqueue_device(d.data_ptr(), cfg.width, cfg.height, n)
+        det.results_to_device(block.data_ptr(), block.data_ptr() + n * S.MAX_MARKERS * S.MARKER_BYTES)
+        markers, counts = det.collect()
+        blocks = S.gather_blocks(block, 0, 1, dist)       # dist.gather over RCCL, no short cut
+        torch.cuda.synchronize()
+        assert len(blocks) == 1 and blocks[0].data_ptr() != block.data_ptr()
+        res = S.unpack(blocks, n, oa.MARKER_DTYPE)
+        assert sorted(res) == list(range(n))
+        for f in range(n):
+            c, m = res[f]
+            assert c == counts[f] >= 1
+            assert m.tobytes() == markers[f, :c].tobytes()
+    finally:
+        dist.destroy_process_group()

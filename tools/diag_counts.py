@@ -16,6 +16,6 @@ d = torch.from_numpy(frames).cuda()
 for _ in range(2):
     det.detect_device(d.data_ptr(), cfg.width, cfg.height, B)
 c = det.counters()
-names = ["frame_cands", "crop_rois", "crop_tiles", "crop_cands", "crop_pixels", "pool_ints", "mid_f", "mid_c", "long_f", "long_c", "dbg_walks", "dbg_steps"]
+names = ["frame_cands", "crop_rois", "crop_tiles", "crop_cands", "crop_pixels", "pool_ints", "mid_f", "mid_c", "long_f", "long_c"]
 print({n: int(v) / B for n, v in zip(names, c)})
 print("stage ms", dict(zip(oa.STAGE_NAMES, det.stage_ms().round(3).tolist())))
