@@ -23,6 +23,7 @@ struct OcvarHip {
     int device = 0;
     Workspace ws{};
     hipStream_t stream = nullptr;
+    hipStream_t hp_stream = nullptr;   // high-priority stream of the latency-bound kernels (env OCVAR_SPLIT_STREAMS=0: off)
     hipStream_t last_stream = nullptr;
     hipEvent_t ev[13]{};   // 12 intervals: see ocvar_hip_stage_ms
     std::vector<void*> allocs;
@@ -76,6 +77,14 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     c->device = device;
     HIP_TRY(c, hipSetDevice(device));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        const char* e = std::getenv("OCVAR_SPLIT_STREAMS");
+        if (!e || std::atoi(e) != 0) {
+            int lo = 0, hi = 0;
+            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi: numerically lowest = greatest priority
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->hp_stream, hipStreamNonBlocking, hi));
+        }
+    }
     for (auto& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
     Workspace& w = c->ws;
     w.max_w = max_width;
@@ -155,6 +164,7 @@ extern "C" void ocvar_hip_destroy(OcvarHip* c) {
     if (c->computed) (void)hipEventDestroy(c->computed);
     if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
     if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
+    if (c->hp_stream) (void)hipStreamDestroy(c->hp_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -185,12 +195,12 @@ static bool trace_launches() {
     static const bool on = std::getenv("OCVAR_TRACE_LAUNCHES") != nullptr;
     return on;
 }
-#define TRACE_LAUNCH(name)                                                               \
+#define TRACE_LAUNCH(name, st)                                                             \
     do {                                                                                 \
         if (trace_launches()) {                                                          \
             std::fprintf(stderr, "ocvar: %s ...", name);                                 \
             std::fflush(stderr);                                                         \
-            hipError_t e_ = hipStreamSynchronize(s);                                     \
+            hipError_t e_ = hipStreamSynchronize(st);                                    \
             std::fprintf(stderr, " %s\n", e_ == hipSuccess ? "ok" : hipGetErrorString(e_)); \
         }                                                                                \
     } while (0)
@@ -243,44 +253,55 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     } else {
         HIP_TRY(c, hipMemsetAsync(w.n_prev, 0, n_frames * sizeof(int), s));
     }
+    // The two streaming kernels (VALU-bound, tens of thousands of workgroups) stay on the caller's stream; the border
+    // followers and the tail -- latency-bound, a few hundred long-lived workgroups -- go to this context's high-priority
+    // stream, so that with several contexts in flight their workgroups are placed ahead of the queued workgroups of
+    // another context's binarise kernel instead of behind them.  The events that time the stages also order the two streams.
+    hipStream_t f = c->hp_stream ? c->hp_stream : s;
+    auto hop = [&](int k, hipStream_t from, hipStream_t to) -> hipError_t {   // ev[k] on `from`; `to` continues after it
+        hipError_t e = hipEventRecord(c->ev[k], from);
+        if (e == hipSuccess && from != to) e = hipStreamWaitEvent(to, c->ev[k], 0);
+        return e;
+    };
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     launch_binarise_frames(w, d_bgr, row_stride, frame_stride, grey_in_place, s);
-    TRACE_LAUNCH("binarise_frames");
-    HIP_TRY(c, hipEventRecord(c->ev[1], s));
-    launch_follow_frames(w, s);
-    TRACE_LAUNCH("follow tier 1 (frames)");
-    HIP_TRY(c, hipEventRecord(c->ev[2], s));
-    launch_follow_mid_frames(w, s);
-    TRACE_LAUNCH("follow tier 2 (frames)");
-    HIP_TRY(c, hipEventRecord(c->ev[3], s));
-    launch_follow_long_frames(w, s);
-    TRACE_LAUNCH("follow tier 3 (frames)");
-    HIP_TRY(c, hipEventRecord(c->ev[4], s));
-    launch_order_and_crops(w, s);
-    TRACE_LAUNCH("order_and_crops");
-    HIP_TRY(c, hipEventRecord(c->ev[5], s));
+    TRACE_LAUNCH("binarise_frames", s);
+    HIP_TRY(c, hop(1, s, f));
+    launch_follow_frames(w, f);
+    TRACE_LAUNCH("follow tier 1 (frames)", f);
+    HIP_TRY(c, hipEventRecord(c->ev[2], f));
+    launch_follow_mid_frames(w, f);
+    TRACE_LAUNCH("follow tier 2 (frames)", f);
+    HIP_TRY(c, hipEventRecord(c->ev[3], f));
+    launch_follow_long_frames(w, f);
+    TRACE_LAUNCH("follow tier 3 (frames)", f);
+    HIP_TRY(c, hipEventRecord(c->ev[4], f));
+    launch_order_and_crops(w, f);
+    TRACE_LAUNCH("order_and_crops", f);
     if (stages > 2) {
+        HIP_TRY(c, hop(5, f, s));
         launch_binarise_crops(w, s);
-        TRACE_LAUNCH("binarise_crops");
-        HIP_TRY(c, hipEventRecord(c->ev[6], s));
-        launch_follow_crops(w, s);
-        TRACE_LAUNCH("follow tier 1 (crops)");
-        HIP_TRY(c, hipEventRecord(c->ev[7], s));
-        launch_follow_mid_crops(w, s);
-        TRACE_LAUNCH("follow tier 2 (crops)");
-        HIP_TRY(c, hipEventRecord(c->ev[8], s));
-        launch_follow_long_crops(w, s);
-        TRACE_LAUNCH("follow tier 3 (crops)");
-        HIP_TRY(c, hipEventRecord(c->ev[9], s));
-        launch_decode(w, s);
-        TRACE_LAUNCH("decode");
-        HIP_TRY(c, hipEventRecord(c->ev[10], s));
-        launch_finalise(w, s);
-        TRACE_LAUNCH("finalise");
-        HIP_TRY(c, hipEventRecord(c->ev[11], s));
+        TRACE_LAUNCH("binarise_crops", s);
+        HIP_TRY(c, hop(6, s, f));
+        launch_follow_crops(w, f);
+        TRACE_LAUNCH("follow tier 1 (crops)", f);
+        HIP_TRY(c, hipEventRecord(c->ev[7], f));
+        launch_follow_mid_crops(w, f);
+        TRACE_LAUNCH("follow tier 2 (crops)", f);
+        HIP_TRY(c, hipEventRecord(c->ev[8], f));
+        launch_follow_long_crops(w, f);
+        TRACE_LAUNCH("follow tier 3 (crops)", f);
+        HIP_TRY(c, hipEventRecord(c->ev[9], f));
+        launch_decode(w, f);
+        TRACE_LAUNCH("decode", f);
+        HIP_TRY(c, hipEventRecord(c->ev[10], f));
+        launch_finalise(w, f);
+        TRACE_LAUNCH("finalise", f);
+        HIP_TRY(c, hop(11, f, s));
         HIP_TRY(c, hipMemcpyAsync(c->h_counts, w.n_markers, n_frames * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipMemcpyAsync(c->h_markers, w.markers, (size_t)n_frames * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToHost, s));
     } else {
+        HIP_TRY(c, hop(5, f, s));
         for (int k = 6; k < 12; k++) HIP_TRY(c, hipEventRecord(c->ev[k], s));
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, w.counters, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));

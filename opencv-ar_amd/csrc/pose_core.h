@@ -5,10 +5,13 @@
 // cvarGlMatrix (133-152) with the acMatrixToQuaternion / acQuaternionToMatrix round trip
 // (/root/reference/src/acmath.cpp:215-276).
 //
-// Same estimator as OpenCV's planar branch (4-point homography -> r1,r2 normalised, r3 = r1 x r2, nearest
-// rotation, then Levenberg-Marquardt on the pixel reprojection error), written for a GPU lane: fixed-size
-// arrays, Newton iteration for the nearest rotation (no SVD), Cholesky for the 6x6 normal equations.
-// The contract is the converged minimum in the same basin (tolerance 1e-4 relative on glMatrix).
+// Same estimator as OpenCV's planar branch (undistorted normalised points -> 4-point homography -> r1,r2 normalised,
+// r3 = r1 x r2, nearest rotation, then Levenberg-Marquardt on the pixel reprojection error of the full camera model:
+// intrinsics + the 5 distortion coefficients k1 k2 p1 p2 k3 of CvarCamera::distCoeffs, as cvFindExtrinsicCameraParams2
+// is handed them, opencvar.cpp:261-272), written for a GPU lane: fixed-size arrays, Newton iteration for the nearest
+// rotation (no SVD), Cholesky for the 6x6 normal equations.  With all coefficients zero (cvarReadCamera(NULL)) the
+// distortion terms are skipped altogether.  The contract is the converged minimum in the same basin (tolerance 1e-4
+// relative on glMatrix).
 #pragma once
 #include "hd.h"
 #include <float.h>
@@ -151,8 +154,9 @@ OCVAR_HD bool rect_homography(double ratio, const double* m, double* H) {
     return true;
 }
 
-// reprojection of the 4 rectangle corners, residual e = proj - img, optional 8x6 Jacobian
-OCVAR_HD void reproject(double ratio, const double* p, const double* K, const double* img, double* e, double* J) {
+// reprojection of the 4 rectangle corners, residual e = proj - img, optional 8x6 Jacobian.  dist: k1 k2 p1 p2 k3 or null
+// (pinhole).
+OCVAR_HD void reproject(double ratio, const double* p, const double* K, const double* dist, const double* img, double* e, double* J) {
     double R[9], dR[27];
     rodrigues(p, R, J ? dR : nullptr);
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
@@ -165,19 +169,52 @@ OCVAR_HD void reproject(double ratio, const double* p, const double* K, const do
         z = z ? 1. / z : 1;
         x *= z;
         y *= z;
-        e[2 * i] = x * fx + cx - img[2 * i];
-        e[2 * i + 1] = y * fy + cy - img[2 * i + 1];
+        if (!dist) {
+            e[2 * i] = x * fx + cx - img[2 * i];
+            e[2 * i + 1] = y * fy + cy - img[2 * i + 1];
+            if (J) {
+                double* jx = J + 12 * i;
+                double* jy = jx + 6;
+                for (int j = 0; j < 3; j++) {
+                    const double* d = dR + 9 * j;
+                    const double dx0 = X * d[0] + Y * d[1], dy0 = X * d[3] + Y * d[4], dz0 = X * d[6] + Y * d[7];
+                    jx[j] = fx * z * (dx0 - x * dz0);
+                    jy[j] = fy * z * (dy0 - y * dz0);
+                }
+                jx[3] = fx * z; jx[4] = 0; jx[5] = -fx * x * z;
+                jy[3] = 0; jy[4] = fy * z; jy[5] = -fy * y * z;
+            }
+            continue;
+        }
+        // cvProjectPoints2: radial (k1 k2 k3) and tangential (p1 p2) distortion of the normalised point
+        const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3], k3 = dist[4];
+        const double r2 = x * x + y * y;
+        const double cd = 1 + (k1 + (k2 + k3 * r2) * r2) * r2;
+        const double xd = x * cd + 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+        const double yd = y * cd + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+        e[2 * i] = xd * fx + cx - img[2 * i];
+        e[2 * i + 1] = yd * fy + cy - img[2 * i + 1];
         if (J) {
             double* jx = J + 12 * i;
             double* jy = jx + 6;
-            for (int j = 0; j < 3; j++) {
-                const double* d = dR + 9 * j;
-                const double dx0 = X * d[0] + Y * d[1], dy0 = X * d[3] + Y * d[4], dz0 = X * d[6] + Y * d[7];
-                jx[j] = fx * z * (dx0 - x * dz0);
-                jy[j] = fy * z * (dy0 - y * dz0);
+            // partial derivatives of the distorted point with respect to the undistorted one
+            const double dcd = 2 * (k1 + (2 * k2 + 3 * k3 * r2) * r2);   // d(cd)/d(r2) * 2: d(cd) = dcd * (x dx + y dy)
+            const double xdx = cd + x * x * dcd + 2 * p1 * y + 6 * p2 * x, xdy = x * y * dcd + 2 * p1 * x + 2 * p2 * y;
+            const double ydx = x * y * dcd + 2 * p1 * x + 2 * p2 * y, ydy = cd + y * y * dcd + 6 * p1 * y + 2 * p2 * x;
+            for (int j = 0; j < 6; j++) {
+                double dx, dy;
+                if (j < 3) {
+                    const double* d = dR + 9 * j;
+                    const double dx0 = X * d[0] + Y * d[1], dy0 = X * d[3] + Y * d[4], dz0 = X * d[6] + Y * d[7];
+                    dx = z * (dx0 - x * dz0);
+                    dy = z * (dy0 - y * dz0);
+                } else {
+                    dx = j == 3 ? z : (j == 5 ? -x * z : 0.0);
+                    dy = j == 4 ? z : (j == 5 ? -y * z : 0.0);
+                }
+                jx[j] = fx * (xdx * dx + xdy * dy);
+                jy[j] = fy * (ydx * dx + ydy * dy);
             }
-            jx[3] = fx * z; jx[4] = 0; jx[5] = -fx * x * z;
-            jy[3] = 0; jy[4] = fy * z; jy[5] = -fy * y * z;
         }
     }
 }
@@ -268,12 +305,26 @@ OCVAR_HD void gl_from_pose(const double* R, const double* t, double* m) {
 
 OCVAR_HD void square_to_glmatrix(const float* sq, const CameraRec& cam, double ratio, double* gl) {
     const double* K = cam.cameraMatrix;
+    const double* kd = cam.distCoeffs;
+    const double* dist = (kd[0] != 0 || kd[1] != 0 || kd[2] != 0 || kd[3] != 0 || kd[4] != 0) ? kd : nullptr;
     double img[8], mn[8];
     for (int i = 0; i < 4; i++) {
         img[2 * i] = sq[2 * i];
         img[2 * i + 1] = sq[2 * i + 1];
-        mn[2 * i] = (img[2 * i] - K[2]) * (1. / K[0]);
-        mn[2 * i + 1] = (img[2 * i + 1] - K[5]) * (1. / K[4]);
+        double x = (img[2 * i] - K[2]) * (1. / K[0]), y = (img[2 * i + 1] - K[5]) * (1. / K[4]);
+        if (dist) {   // cvUndistortPoints: 5 fixed-point iterations of the inverse distortion
+            const double x0 = x, y0 = y;
+            for (int it = 0; it < 5; it++) {
+                const double r2 = x * x + y * y;
+                const double icd = 1. / (1 + ((dist[4] * r2 + dist[1]) * r2 + dist[0]) * r2);
+                const double ddx = 2 * dist[2] * x * y + dist[3] * (r2 + 2 * x * x);
+                const double ddy = dist[2] * (r2 + 2 * y * y) + 2 * dist[3] * x * y;
+                x = (x0 - ddx) * icd;
+                y = (y0 - ddy) * icd;
+            }
+        }
+        mn[2 * i] = x;
+        mn[2 * i + 1] = y;
     }
     double p[6] = {0, 0, 0, 0, 0, 0};
     double h[9];
@@ -296,7 +347,7 @@ OCVAR_HD void square_to_glmatrix(const float* sq, const CameraRec& cam, double r
     int lambdaLg10 = -3;
     double prevErr = DBL_MAX;
     for (int iters = 0;;) {
-        reproject(ratio, p, K, img, e, J);
+        reproject(ratio, p, K, dist, img, e, J);
         for (int i = 0; i < 6; i++) {
             for (int j = 0; j < 6; j++) {
                 double s = 0;
@@ -312,7 +363,7 @@ OCVAR_HD void square_to_glmatrix(const float* sq, const CameraRec& cam, double r
         double errNorm;
         for (bool first = true;; first = false) {
             if (!first) {
-                reproject(ratio, p, K, img, e, nullptr);
+                reproject(ratio, p, K, dist, img, e, nullptr);
                 errNorm = norm_n(e, 8);
                 if (!(errNorm > prevErr && ++lambdaLg10 <= 16)) break;
             }

@@ -102,7 +102,8 @@ void orc_camera_scale(OrcCamera* cam, int width, int height);
 /* ---- pose (A.12 + opencvar.cpp:133-152) ---- */
 void orc_rodrigues_vec2mat(const double* r, double* R9, double* J27);
 void orc_rodrigues_mat2vec(const double* R9, double* r);
-void orc_find_extrinsic(const double* obj12, const double* img8, const double* K9, double* rvec, double* tvec);
+/* dist5: (k1, k2, p1, p2, k3) or NULL */
+void orc_find_extrinsic(const double* obj12, const double* img8, const double* K9, const double* dist5, double* rvec, double* tvec);
 void orc_gl_matrix(const double* R9, const double* t3, double* m16);
 void orc_square_to_matrix(const float* pts8, const OrcCamera* cam, double ratio, double* m16);
 

@@ -122,37 +122,52 @@ bool homography4(const double* M, const double* m, double* H) {
     return true;
 }
 
-void project(const double* obj, const double* r, const double* t, const double* K, double* proj, double* J /*8x6 or null*/) {
+// cvProjectPoints2 with the 5-coefficient distortion model k = (k1, k2, p1, p2, k3) and its Jacobian with respect to
+// (rvec, tvec) (OpenCV 2.4 calibration.cpp; dist == nullptr or all zero: the pinhole projection)
+void project(const double* obj, const double* r, const double* t, const double* K, const double* dist, double* proj,
+             double* J /*8x6 or null*/) {
     double R[9], dRdr[27];
     orc_rodrigues_vec2mat(r, R, dRdr);
-    double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    double k[5] = {0, 0, 0, 0, 0};
+    if (dist)
+        for (int i = 0; i < 5; i++) k[i] = dist[i];
     for (int i = 0; i < 4; i++) {
-        double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+        const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
         double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
         double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
         double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
         z = z ? 1. / z : 1;
         x *= z;
         y *= z;
-        proj[2 * i] = x * fx + cx;
-        proj[2 * i + 1] = y * fy + cy;
+        const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+        const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+        const double cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+        const double xd = x * cdist + k[2] * a1 + k[3] * a2;
+        const double yd = y * cdist + k[2] * a3 + k[3] * a1;
+        proj[2 * i] = xd * fx + cx;
+        proj[2 * i + 1] = yd * fy + cy;
         if (J) {
             double* jx = J + (2 * i) * 6;
             double* jy = J + (2 * i + 1) * 6;
+            double dxp[6], dyp[6];   // d(x)/d(param), d(y)/d(param) of the undistorted normalised point
             for (int j = 0; j < 3; j++) {
                 const double* d = dRdr + j * 9;
-                double dx0 = X * d[0] + Y * d[1] + Z * d[2];
-                double dy0 = X * d[3] + Y * d[4] + Z * d[5];
-                double dz0 = X * d[6] + Y * d[7] + Z * d[8];
-                jx[j] = fx * z * (dx0 - x * dz0);
-                jy[j] = fy * z * (dy0 - y * dz0);
+                const double dx0 = X * d[0] + Y * d[1] + Z * d[2];
+                const double dy0 = X * d[3] + Y * d[4] + Z * d[5];
+                const double dz0 = X * d[6] + Y * d[7] + Z * d[8];
+                dxp[j] = z * (dx0 - x * dz0);
+                dyp[j] = z * (dy0 - y * dz0);
             }
-            jx[3] = fx * z;
-            jx[4] = 0;
-            jx[5] = fx * (-x * z);
-            jy[3] = 0;
-            jy[4] = fy * z;
-            jy[5] = fy * (-y * z);
+            dxp[3] = z; dxp[4] = 0; dxp[5] = -x * z;
+            dyp[3] = 0; dyp[4] = z; dyp[5] = -y * z;
+            for (int j = 0; j < 6; j++) {
+                const double dr2 = 2 * x * dxp[j] + 2 * y * dyp[j];
+                const double dcdist = k[0] * dr2 + 2 * k[1] * r2 * dr2 + 3 * k[4] * r4 * dr2;
+                const double da1 = 2 * (x * dyp[j] + y * dxp[j]);
+                jx[j] = fx * (dxp[j] * cdist + x * dcdist + k[2] * da1 + k[3] * (dr2 + 4 * x * dxp[j]));
+                jy[j] = fy * (dyp[j] * cdist + y * dcdist + k[2] * (dr2 + 4 * y * dyp[j]) + k[3] * da1);
+            }
         }
     }
 }
@@ -237,13 +252,27 @@ extern "C" void orc_rodrigues_mat2vec(const double* Rin, double* r) {
     r[2] = rz;
 }
 
-extern "C" void orc_find_extrinsic(const double* obj, const double* img, const double* K, double* rvec, double* tvec) {
+extern "C" void orc_find_extrinsic(const double* obj, const double* img, const double* K, const double* dist, double* rvec, double* tvec) {
     double param[6] = {0, 0, 0, 0, 0, 0};
-    // normalised image points (zero distortion -> undistort is the identity)
+    // normalised image points: cvUndistortPoints, 5 fixed-point iterations of the inverse distortion (the identity for
+    // zero coefficients)
+    double k[5] = {0, 0, 0, 0, 0};
+    if (dist)
+        for (int i = 0; i < 5; i++) k[i] = dist[i];
     double mn[8], Mxy[8];
     for (int i = 0; i < 4; i++) {
-        mn[2 * i] = (img[2 * i] - K[2]) * (1. / K[0]);
-        mn[2 * i + 1] = (img[2 * i + 1] - K[5]) * (1. / K[4]);
+        double x = (img[2 * i] - K[2]) * (1. / K[0]), y = (img[2 * i + 1] - K[5]) * (1. / K[4]);
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1. / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        mn[2 * i] = x;
+        mn[2 * i + 1] = y;
         Mxy[2 * i] = obj[3 * i];  // object plane is z = 0: R_transform = I, T_transform = -centroid = 0
         Mxy[2 * i + 1] = obj[3 * i + 1];
     }
@@ -286,7 +315,7 @@ extern "C" void orc_find_extrinsic(const double* obj, const double* img, const d
     int lambdaLg10 = -3, iters = 0;
     double prevErrNorm = DBL_MAX;
     for (;;) {
-        project(obj, param, param + 3, K, proj, J);
+        project(obj, param, param + 3, K, dist, proj, J);
         for (int i = 0; i < 8; i++) err[i] = proj[i] - img[i];
         for (int i = 0; i < 6; i++) {
             for (int j = 0; j < 6; j++) {
@@ -310,7 +339,7 @@ extern "C" void orc_find_extrinsic(const double* obj, const double* img, const d
         if (iters == 0) prevErrNorm = norm_n(err, 8);
         double errNorm;
         for (;;) {
-            project(obj, param, param + 3, K, proj, nullptr);
+            project(obj, param, param + 3, K, dist, proj, nullptr);
             for (int i = 0; i < 8; i++) err[i] = proj[i] - img[i];
             errNorm = norm_n(err, 8);
             if (errNorm > prevErrNorm) {
@@ -352,7 +381,7 @@ extern "C" void orc_square_to_matrix(const float* pts, const OrcCamera* cam, dou
     double img[8];
     for (int i = 0; i < 8; i++) img[i] = pts[i];
     double rvec[3], tvec[3], R[9];
-    orc_find_extrinsic(obj, img, cam->cameraMatrix, rvec, tvec);
+    orc_find_extrinsic(obj, img, cam->cameraMatrix, cam->distCoeffs, rvec, tvec);
     orc_rodrigues_vec2mat(rvec, R, nullptr);
     orc_gl_matrix(R, tvec, m16);
 }

@@ -5,56 +5,87 @@
 //   opencvar.cpp:514  cvWarpPerspective(crop, pat, M32)          
 //   opencvar.cpp:723-724 cvCvtColor + cvThreshold(>100 -> 1)     
 //   opencvar.cpp:728  acArray2DToBit on a widthStep-aligned buffer with stride w (quirk D1)
-// The 8x8 system is solved by Gaussian elimination with partial pivoting in double (OpenCV 2.4 uses
-// an SVD solve; both are double and the result is rounded to float32 -- parity unpinned).
+// The 8x8 system is solved the way OpenCV 2.4 does it -- cvSolve(..., CV_SVD): a one-sided (Hestenes) Jacobi SVD in
+// double, x = V diag(1/w) U^T b -- and the result is rounded to float32.  This is deliberately NOT the device path's
+// solver (Gaussian elimination with partial pivoting, opencv-ar_amd/csrc/decode_core.h): the two agree to a few ulps of
+// double, and the parity tests / tools/fuzz_parity.py show whether that ever survives the rounding to float32 and the
+// 1/32-pixel quantisation of the warp into a different code bit (recorded in DESIGN.md section 5).  Parity unpinned: the
+// sweep order and stopping rule of OpenCV's own JacobiSVD are not reproduced bit for bit.
 #include "oracle.h"
 #include <cmath>
 #include <cstring>
 #include <vector>
 
-static bool solve8(double A[8][9]) {
-    for (int c = 0; c < 8; c++) {
-        int piv = c;
-        double best = fabs(A[c][c]);
-        for (int r = c + 1; r < 8; r++)
-            if (fabs(A[r][c]) > best) {
-                best = fabs(A[r][c]);
-                piv = r;
-            }
-        if (best == 0.0) return false;
-        if (piv != c)
-            for (int k = 0; k < 9; k++) {
-                double t = A[c][k];
-                A[c][k] = A[piv][k];
-                A[piv][k] = t;
-            }
-        for (int r = c + 1; r < 8; r++) {
-            double f = A[r][c] / A[c][c];
-            for (int k = c; k < 9; k++) A[r][k] = A[r][k] - f * A[c][k];
+// x = pinv(A) b for an 8x8 A (row-major) by one-sided Jacobi: columns of W = A V are made mutually orthogonal by plane
+// rotations accumulated in V; then w_j = |W_j|, U_j = W_j / w_j.
+static bool solve8_svd(const double A[8][8], const double b[8], double x[8]) {
+    double W[8][8], V[8][8];
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++) {
+            W[i][j] = A[i][j];
+            V[i][j] = i == j ? 1.0 : 0.0;
         }
+    for (int sweep = 0; sweep < 60; sweep++) {
+        bool rotated = false;
+        for (int p = 0; p < 7; p++)
+            for (int q = p + 1; q < 8; q++) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 8; i++) {
+                    alpha += W[i][p] * W[i][p];
+                    beta += W[i][q] * W[i][q];
+                    gamma += W[i][p] * W[i][q];
+                }
+                if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 2.220446049250313e-16 * sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < 8; i++) {
+                    const double wp = W[i][p], wq = W[i][q];
+                    W[i][p] = c * wp - sn * wq;
+                    W[i][q] = sn * wp + c * wq;
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = c * vp - sn * vq;
+                    V[i][q] = sn * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
     }
-    for (int c = 7; c >= 0; c--) {
-        double s = A[c][8];
-        for (int k = c + 1; k < 8; k++) s = s - A[c][k] * A[k][8];
-        A[c][8] = s / A[c][c];
+    double wmax = 0, w[8];
+    for (int j = 0; j < 8; j++) {
+        double n2 = 0;
+        for (int i = 0; i < 8; i++) n2 += W[i][j] * W[i][j];
+        w[j] = sqrt(n2);
+        if (w[j] > wmax) wmax = w[j];
+    }
+    if (wmax == 0.0) return false;
+    for (int i = 0; i < 8; i++) x[i] = 0.0;
+    for (int j = 0; j < 8; j++) {
+        if (w[j] <= 8 * 2.220446049250313e-16 * wmax) continue;   // cvSVBkSb: singular values below the threshold are dropped
+        double ub = 0;
+        for (int i = 0; i < 8; i++) ub += W[i][j] * b[i];
+        const double f = ub / (w[j] * w[j]);   // (U_j . b) / w_j with U_j = W_j / w_j
+        for (int i = 0; i < 8; i++) x[i] += V[i][j] * f;
     }
     return true;
 }
 
 extern "C" void orc_get_perspective_transform(const float* src, const float* dst, float* m) {
-    double A[8][9];
+    double A[8][8], b[8], x[8];
     for (int i = 0; i < 4; i++) {
-        double sx = src[2 * i], sy = src[2 * i + 1], dx = dst[2 * i], dy = dst[2 * i + 1];
-        double r0[9] = {sx, sy, 1, 0, 0, 0, -sx * dx, -sy * dx, dx};
-        double r1[9] = {0, 0, 0, sx, sy, 1, -sx * dy, -sy * dy, dy};
+        const double sx = src[2 * i], sy = src[2 * i + 1], dx = dst[2 * i], dy = dst[2 * i + 1];
+        const double r0[8] = {sx, sy, 1, 0, 0, 0, -sx * dx, -sy * dx};
+        const double r1[8] = {0, 0, 0, sx, sy, 1, -sx * dy, -sy * dy};
         memcpy(A[i], r0, sizeof r0);
         memcpy(A[i + 4], r1, sizeof r1);
+        b[i] = dx;
+        b[i + 4] = dy;
     }
-    if (!solve8(A)) {
+    if (!solve8_svd(A, b, x)) {
         for (int i = 0; i < 9; i++) m[i] = 0;
         return;
     }
-    for (int i = 0; i < 8; i++) m[i] = (float)A[i][8];
+    for (int i = 0; i < 8; i++) m[i] = (float)x[i];
     m[8] = 1.0f;
 }
 

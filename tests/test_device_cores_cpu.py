@@ -128,3 +128,59 @@ def test_decode_and_pose_cores(emul):
             emul.emul_square_to_glmatrix(P(sq), C.byref(cam), 1.0, P(g2))
             assert np.abs(g1 - g2).max() <= 1e-6 * max(1.0, np.abs(g1).max())
     assert nbits > 40
+
+
+DIST = [-0.21, 0.09, 0.0015, -0.0008, -0.02]   # k1 k2 p1 p2 k3 of a moderately distorting lens
+
+
+def _project_rect(ratio, rvec, tvec, K, k):
+    """numpy statement of the camera model cvFindExtrinsicCameraParams2 fits (pinhole + 5-coefficient distortion)"""
+    th = np.linalg.norm(rvec)
+    kx = rvec / th
+    Kx = np.array([[0, -kx[2], kx[1]], [kx[2], 0, -kx[0]], [-kx[1], kx[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    out = []
+    for X, Y in [(-ratio, -1), (ratio, -1), (ratio, 1), (-ratio, 1)]:
+        p = R @ np.array([X, Y, 0.0]) + tvec
+        x, y = p[0] / p[2], p[1] / p[2]
+        r2 = x * x + y * y
+        cd = 1 + k[0] * r2 + k[1] * r2 ** 2 + k[4] * r2 ** 3
+        xd = x * cd + 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x)
+        yd = y * cd + k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y
+        out.append([xd * K[0] + K[2], yd * K[4] + K[5]])
+    return np.array(out), R
+
+
+def test_pose_with_lens_distortion(emul):
+    """CvarCamera::distCoeffs reach cvFindExtrinsicCameraParams2 in the reference (opencvar.cpp:261-272).  A known pose is
+    projected through the full camera model; both the oracle and the device core must recover it (the quad is exact, so
+    the reprojection minimum is the pose itself), and agree with each other far inside the 1e-4 bar."""
+    o = H.oracle()
+    o.orc_gl_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    cam = H.oracle_camera(1280, 720)
+    for i in range(5):
+        cam.distCoeffs[i] = DIST[i]
+    K = np.array(list(cam.cameraMatrix))
+    for trial in range(40):
+        rvec = rng.normal(size=3) * 0.5
+        rvec[2] += rng.uniform(-2, 2)
+        tvec = np.array([rng.uniform(-3, 3), rng.uniform(-2, 2), rng.uniform(8, 25)])
+        ratio = float(rng.choice([1.0, 0.75]))
+        img, R = _project_rect(ratio, rvec, tvec, K, DIST)
+        sq = np.ascontiguousarray(img.astype(np.float32).reshape(-1))
+        # ground truth from the float32-rounded corners is the pose up to that rounding: compare loosely with it, tightly
+        # between the two solvers
+        want = np.zeros(16)
+        o.orc_gl_matrix(P(np.ascontiguousarray(R.reshape(-1))), P(tvec), P(want))
+        g1, g2 = np.zeros(16), np.zeros(16)
+        o.orc_square_to_matrix(P(sq), C.byref(cam), C.c_double(ratio), P(g1))
+        emul.emul_square_to_glmatrix(P(sq), C.byref(cam), C.c_double(ratio), P(g2))
+        scale = max(1.0, np.abs(want).max())
+        assert np.abs(g1 - want).max() <= 2e-3 * scale, (trial, g1, want)
+        assert np.abs(g1 - g2).max() <= 1e-6 * scale, trial
+    # and the coefficients matter: the pinhole solution for the same corners is a different pose
+    pin = H.oracle_camera(1280, 720)
+    g3 = np.zeros(16)
+    o.orc_square_to_matrix(P(sq), C.byref(pin), C.c_double(ratio), P(g3))
+    assert np.abs(g3 - g1).max() > 1e-3

@@ -371,3 +371,26 @@ def test_capacity_overflow_is_loud_not_wrong(oa):
         assert "-4" in str(e) or "overflow" in str(e)
         return
     check_frame(det, 0, frame, tpls, cam, markers, counts)
+
+
+def test_camera_with_lens_distortion(oa):
+    """A calibrated camera (cvarReadCamera(file): non-zero distCoeffs) reaches the pose solver as in the reference
+    (opencvar.cpp:261-272): glMatrix of every marker against the oracle's full-camera-model solve."""
+    cfg = H.synth_config(2)
+    names = ["2x2-01"]
+    tpls = H.oracle_templates(names)
+    cam = H.oracle_camera(cfg.width, cfg.height)
+    for i, v in enumerate([-0.21, 0.09, 0.0015, -0.0008, -0.02]):
+        cam.distCoeffs[i] = v
+    det = oa.Detector(cfg.width, cfg.height, max_batch=3)
+    det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls])
+    det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+    frames = np.stack([H.synth_frame(cfg, f, names)[0] for f in (0, 5, 9)])
+    markers, counts = det.detect_host(frames.copy())
+    pin = H.oracle_camera(cfg.width, cfg.height)
+    moved = 0
+    for f in range(3):
+        ref_m, _ = check_frame(det, f, frames[f], tpls, cam, markers, counts)
+        ref_pin, _, _ = H.oracle_registration(frames[f], tpls, pin)
+        moved += sum(np.abs(np.array(a.glMatrix) - np.array(b.glMatrix)).max() > 1e-3 for a, b in zip(ref_m, ref_pin))
+    assert moved >= 1   # the coefficients change the pose: the test would notice a solver that ignores them
