@@ -23,7 +23,7 @@ struct OcvarHip {
     int device = 0;
     Workspace ws{};
     hipStream_t stream = nullptr;
-    hipStream_t hp_stream = nullptr;   // high-priority stream of the latency-bound kernels (env OCVAR_SPLIT_STREAMS=0: off)
+    hipStream_t hp_stream = nullptr;   // high-priority stream of the latency-bound kernels (env OCVAR_SPLIT_STREAMS=1; default off)
     hipStream_t last_stream = nullptr;
     hipEvent_t ev[13]{};   // 12 intervals: see ocvar_hip_stage_ms
     std::vector<void*> allocs;
@@ -79,7 +79,7 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {
         const char* e = std::getenv("OCVAR_SPLIT_STREAMS");
-        if (!e || std::atoi(e) != 0) {
+        if (e && std::atoi(e) != 0) {
             int lo = 0, hi = 0;
             HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi: numerically lowest = greatest priority
             HIP_TRY(c, hipStreamCreateWithPriority(&c->hp_stream, hipStreamNonBlocking, hi));
@@ -253,10 +253,12 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     } else {
         HIP_TRY(c, hipMemsetAsync(w.n_prev, 0, n_frames * sizeof(int), s));
     }
-    // The two streaming kernels (VALU-bound, tens of thousands of workgroups) stay on the caller's stream; the border
-    // followers and the tail -- latency-bound, a few hundred long-lived workgroups -- go to this context's high-priority
-    // stream, so that with several contexts in flight their workgroups are placed ahead of the queued workgroups of
-    // another context's binarise kernel instead of behind them.  The events that time the stages also order the two streams.
+    // Optional (OCVAR_SPLIT_STREAMS=1): the two streaming kernels (VALU-bound, tens of thousands of workgroups) stay on the
+    // caller's stream, the border followers and the tail -- latency-bound, a few hundred long-lived workgroups -- go to
+    // this context's high-priority stream, so that with several contexts in flight their workgroups are placed ahead of
+    // the queued workgroups of another context's binarise kernel.  Measured with 4 contexts: the followers' in-region
+    // durations halve, binarise's grows by as much (138 k vs 142 k frames/s) -- off by default.  The events that time
+    // the stages also order the two streams.
     hipStream_t f = c->hp_stream ? c->hp_stream : s;
     auto hop = [&](int k, hipStream_t from, hipStream_t to) -> hipError_t {   // ev[k] on `from`; `to` continues after it
         hipError_t e = hipEventRecord(c->ev[k], from);
