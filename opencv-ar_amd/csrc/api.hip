@@ -117,6 +117,7 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     w.cap_long = (int)std::min<size_t>(std::max<size_t>(B * 4096, (size_t)1 << 18), (size_t)1 << 28);   // survivors of tier 1 / tier 2: a noise frame has ~10^4
     if ((rc = dev_alloc(c, &w.mid_frame, (size_t)w.cap_long))) return rc;
     if ((rc = dev_alloc(c, &w.mid_crop, (size_t)w.cap_long))) return rc;
+    if ((rc = dev_alloc(c, &w.mid_first_crop, (size_t)w.cap_long))) return rc;
     if ((rc = dev_alloc(c, &w.long_frame, (size_t)w.cap_long))) return rc;
     if ((rc = dev_alloc(c, &w.long_crop, (size_t)w.cap_long))) return rc;
     if ((rc = dev_alloc(c, &w.quads_frame, B * MAXQ))) return rc;

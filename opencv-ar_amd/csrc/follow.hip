@@ -344,11 +344,30 @@ __device__ __forceinline__ bool wave_finish_packed(const Workspace& ws, const St
     const int lane = threadIdx.x & 63;
     if (npts < 4) return false;
     unsigned lo = 0xffffffffu, hi = 0u;
-    for (int i = lane; i < npts; i += 64) {
-        const unsigned p = gsrc[i];
-        if (STAGE) lpts[i] = p;
-        lo = pk_min(lo, p);
-        hi = pk_max(hi, p);
+    if (STAGE) {
+        // all loads of the border are issued before the first one is consumed: one memory latency for the staging instead
+        // of one per 64 points (the walks of the wave's other lanes stand still meanwhile)
+        unsigned v[LDS_PTS / 64];
+#pragma unroll
+        for (int k = 0; k < LDS_PTS / 64; k++) {
+            const int i = lane + 64 * k;
+            v[k] = i < npts ? gsrc[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < LDS_PTS / 64; k++) {
+            const int i = lane + 64 * k;
+            if (i < npts) {
+                lpts[i] = v[k];
+                lo = pk_min(lo, v[k]);
+                hi = pk_max(hi, v[k]);
+            }
+        }
+    } else {
+        for (int i = lane; i < npts; i += 64) {
+            const unsigned p = gsrc[i];
+            lo = pk_min(lo, p);
+            hi = pk_max(hi, p);
+        }
     }
     lo = wave_pk_min(lo);
     hi = wave_pk_max(hi);
@@ -391,8 +410,15 @@ __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand
         // budget before getting there anyway).
         if (!c.is_hole && earlier_start_behind(pl.nbr, pl.ns, pl.plane, c.pos, 0, BACK_STEPS)) return 0;
         // crops: no border of a crop is longer than tier 2's budget by much (the crop's own frame border is ~4 sides of
-        // <= 260 pixels), so the probe would only repeat what tier 2 does anyway
-        if (CROP) return 1;
+        // <= 260 pixels), so the probe would only repeat what tier 2 does anyway.  A border that starts on the inner edge
+        // of the crop's zeroed frame is (nearly always) the background's own outer border, ~800 steps around the crop: the
+        // longest walk of its crop, so tier 2 is handed these first (route 3) -- its duration is its longest lane's chain,
+        // and a lane that picked such a border up late was that chain.  (Handing them to the wave tier instead was slower:
+        // 64 x 64 windows along four sides cost ~150 us of dependent window loads per border.)
+        if (CROP) {
+            const int x = c.pos % pl.ns, y = c.pos / pl.ns;
+            return (x == 1 || y == 1) ? 3 : 1;
+        }
         const LeanTrace lt = trace_flat(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, nullptr, 0, BUDGET);
         if (lt.status == TRACE_OVERRUN) return lt.npts <= 2 ? 2 : 1;
         if (lt.status != TRACE_OK || lt.npts < 4) return 0;
@@ -492,9 +518,9 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
             }
         }
 #pragma unroll
-        for (int target = 1; target <= (TIER == 1 ? 2 : 1); target++) {
-            StartCand* list = (TIER == 1 && target == 2) ? (CROP ? ws.long_crop : ws.long_frame) : longs;
-            int* count = (TIER == 1 && target == 2) ? ws.counters + (CROP ? CNT_LONG_C : CNT_LONG_F) : n_long;
+        for (int target = 1; target <= (TIER == 1 ? (CROP ? 3 : 2) : 1); target++) {
+            StartCand* list = (TIER == 1 && target == 2) ? (CROP ? ws.long_crop : ws.long_frame) : (target == 3 ? ws.mid_first_crop : longs);
+            int* count = (TIER == 1 && target == 2) ? ws.counters + (CROP ? CNT_LONG_C : CNT_LONG_F) : (target == 3 ? ws.counters + CNT_MID_C_FIRST : n_long);
             const bool queue = route == target;
             const unsigned long long mask = __ballot(queue);
             if (!mask) continue;
@@ -523,6 +549,8 @@ constexpr int MID_BLOCK = 32;
 // the odd row length spreads the lanes over the banks) and appended to the slabs after every block of steps, two lanes'
 // rows per store instruction, each a contiguous run of up to 128 bytes.
 constexpr int POINT_ROW = MID_BLOCK + 1;
+constexpr int FLUSH_W = MID_BLOCK <= 16 ? 16 : 32;   // lanes that carry one walk's parked points in a flush (>= MID_BLOCK)
+static_assert(FLUSH_W >= MID_BLOCK && 64 % FLUSH_W == 0, "a group of lanes covers a whole row of parked points");
 
 template <bool CROP>
 __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
@@ -532,6 +560,10 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
     StartCand* longs = CROP ? ws.long_crop : ws.long_frame;
     int n = ws.counters[CROP ? CNT_MID_C : CNT_MID_F];
     if (n > ws.cap_long) n = ws.cap_long;
+    // crops: the starts tier 1 expects to be the longest walks come first in the ticket order
+    int n_first = CROP ? ws.counters[CNT_MID_C_FIRST] : 0;
+    if (n_first > ws.cap_long) n_first = ws.cap_long;
+    n += n_first;
     int* ticket = ws.counters + (CROP ? CNT_TICKET_MC : CNT_TICKET_MF);
     int* n_long = ws.counters + (CROP ? CNT_LONG_C : CNT_LONG_F);
     const int lane = threadIdx.x & 63;
@@ -568,7 +600,7 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
             if (!have) {
                 const int idx = base + __popcll(idle & below);
                 if (idx < n) {
-                    c = cands[idx];
+                    c = (CROP && idx < n_first) ? ws.mid_first_crop[idx] : cands[idx - n_first];
                     pl = plane_of<CROP>(ws, c.roi);
                     if (c.pos > 0 && c.pos < pl.plane) {
                         flat_begin(w, pl.nbr, pl.ns, c.pos, c.is_hole);
@@ -583,26 +615,31 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
             const bool running = have && w.status < 0;
             if (__ballot(running) == 0) break;
             if (running)
-                flat_step_t(w, pl.nbr, pl.ns, pl.plane, c.pos, budget, [&](bool emit, int x, int y) {
+                flat_step_t<false>(w, pl.nbr, pl.ns, pl.plane, c.pos, budget, [&](bool emit, int x, int y) {
                     my_row[(emit && w.npts < SLAB_PTS) ? w.npts - flushed : MID_BLOCK] = (unsigned)x | ((unsigned)y << 16);
                 });
         }
-        {   // append the parked points to the slabs: lanes 0..31 carry one walk's row, lanes 32..63 the next one's
+        // the step budget is checked here, once per block, instead of in every step (a walk may overshoot it by up to
+        // MID_BLOCK - 1 steps; it is handed to the wave tier either way, which follows the border again from its start)
+        if (have && w.status < 0 && w.step >= budget) w.status = TRACE_OVERRUN;
+        {   // append the parked points to the slabs: every group of FLUSH_W lanes carries one walk's row per store
             const int stored = w.npts < SLAB_PTS ? w.npts : SLAB_PTS;
             const int pend = have ? stored - flushed : 0;
             unsigned long long fm = __ballot(pend > 0);
             if (fm) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            const int grp = lane / FLUSH_W, k = lane % FLUSH_W;
             while (fm) {
-                const int La = __ffsll((long long)fm) - 1;
-                fm &= fm - 1;
-                const int Lb = fm ? __ffsll((long long)fm) - 1 : La;
-                const int cb = fm ? __builtin_amdgcn_readlane(pend, Lb) : 0;
-                fm &= fm - 1;   // (0 & -1 stays 0)
-                const int ca = __builtin_amdgcn_readlane(pend, La);
-                const int oa = __builtin_amdgcn_readlane(flushed, La), ob = __builtin_amdgcn_readlane(flushed, Lb);
-                const bool hi = lane >= 32;
-                const int k = lane & 31;
-                const int L = hi ? Lb : La, cnt = hi ? cb : ca, off = hi ? ob : oa;
+                int L = 0, cnt = 0, off = 0;
+#pragma unroll
+                for (int g = 0; g < 64 / FLUSH_W; g++) {
+                    const int Lg = fm ? __ffsll((long long)fm) - 1 : 0;
+                    const int cg = fm ? __builtin_amdgcn_readlane(pend, Lg) : 0;
+                    const int og = __builtin_amdgcn_readlane(flushed, Lg);
+                    fm &= fm - 1;   // (0 & -1 stays 0)
+                    L = grp == g ? Lg : L;
+                    cnt = grp == g ? cg : cnt;
+                    off = grp == g ? og : off;
+                }
                 if (k < cnt) wave_slabs[(size_t)L * SLAB_STRIDE + off + k] = wave_rows[L * POINT_ROW + k];
             }
             flushed += pend;

@@ -46,7 +46,7 @@ struct CandRec {   // pre-dedupe candidate, slot [frame][quad][template]
 enum { CNT_FRAME_CANDS = 0, CNT_CROP_ROIS = 1, CNT_CROP_TILES = 2, CNT_CROP_CANDS = 3,
        CNT_POOL_INTS = 4 /* 64-bit, uses 4..5 */, CNT_CROP_QUADS = 6, CNT_TICKET_F = 7, CNT_TICKET_C = 8, CNT_ERR = 9,
        CNT_CROP_PIXELS = 10 /* 64-bit, uses 10..11 */, CNT_LONG_F = 12, CNT_LONG_C = 13, CNT_TICKET_LF = 14, CNT_TICKET_LC = 15,
-       CNT_MID_F = 16, CNT_MID_C = 17, CNT_TICKET_MF = 18, CNT_TICKET_MC = 19, CNT_TICKET_BC = 20, CNT_COUNT = 24 };
+       CNT_MID_F = 16, CNT_MID_C = 17, CNT_TICKET_MF = 18, CNT_TICKET_MC = 19, CNT_TICKET_BC = 20, CNT_MID_C_FIRST = 21, CNT_COUNT = 24 };
 
 struct Workspace {
     // limits
@@ -67,6 +67,7 @@ struct Workspace {
     StartCand* cands_crop;
     StartCand* mid_frame;   // starts whose border exceeded tier 1's step budget
     StartCand* mid_crop;
+    StartCand* mid_first_crop;   // crop starts tier 2 takes first (expected longest walks), counter CNT_MID_C_FIRST, capacity cap_long
     StartCand* long_frame;  // starts whose border exceeded tier 2's step budget
     StartCand* long_crop;
     int cap_long;

@@ -328,13 +328,14 @@ OCVAR_HD void flat_begin(FlatWalk& w, const uint8_t* nbr, int ns, int cpos, int 
 // one step of a running walk (w.status < 0).  store(emit, x, y) is called once per step between the request for
 // the next mask and the state update: emit = the pixel being left is a corner point, x/y its position (the caller decides
 // where a point -- or the dummy of a step without one -- goes; see flat_step and follow.hip's tier 2).
-template <class Store>
+// BUDGET = false: the step budget is not looked at (the caller checks w.step between blocks of steps instead).
+template <bool BUDGET = true, class Store>
 OCVAR_HD void flat_step_t(FlatWalk& w, const uint8_t* nbr, int ns, int plane, int cpos, int max_steps, Store&& store) {
     const int from = (w.s + 1) & 7;
     const int t = __builtin_ctz(((w.m * 0x101u) >> from) & 0xffu);   // zero neighbours passed before the next border pixel
     const int e = (from + t) & 7;                                     // exit direction
     const unsigned passed = ((((1u << t) - 1u) * 0x101u) << from) >> 8;   // 8-bit rotate of t ones to position `from`
-    const bool budget = w.step >= max_steps;
+    const bool budget = BUDGET && w.step >= max_steps;
     const bool nf = !budget && (((passed & 0x10u) != 0 && w.idx < cpos) || ((passed & 1u) != 0 && w.idx + 1 < cpos));
     const int dx = step_dx(e), dy = step_dy(e);
     const int nidx = w.idx + mul_small(dy, ns) + dx;
