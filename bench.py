@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config id (3 = headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-frame-per-call latency leg (child process)")
+    ap.add_argument("--no-check", action="store_true", help="skip the result check before the warm-up (profile runs: keeps every launch of a kernel full-size)")
     args = ap.parse_args()
 
     import torch
@@ -202,7 +203,8 @@ def main():
             last.pop(i)
         return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
 
-    check_results(dets[0], d_frames.data_ptr(), cfg, truths, W, Hh, min(8, uniq, sub[0]))
+    if not args.no_check:
+        check_results(dets[0], d_frames.data_ptr(), cfg, truths, W, Hh, min(8, uniq, sub[0]))
     if args.warmup > 0:
         markers, counts = run(args.warmup, False)
     if dist is not None:

@@ -1,7 +1,7 @@
 // decode.hip -- per-quad code readout and the per-frame tail (dedupe, pose, marker records) on gfx950.
 //
 // decode_kernel replaces the inner template loop of cvarArMultRegistration
-// (/root/reference/src/opencvar.cpp:700-774) for one frame-pass quad per lane.  The reference re-runs the whole
+// (/root/reference/src/opencvar.cpp:700-774) for one frame-pass quad per wave.  The reference re-runs the whole
 // square finder on the crop once per template with an identical result; here the crop pass ran
 // once and every template reads the same crop quad.  Templates are visited in order inside the lane because
 // the orient 2/4 corner rotation of one template leaks into the next.
@@ -11,43 +11,97 @@
 
 namespace ocvar {
 
-// (register budget of 4 waves per SIMD = 128 VGPRs: the binarise kernels of other contexts fill the SIMDs with 7 waves of
-// 70 VGPRs, and a wave that needs 246 registers waits until most of them have drained)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void decode_kernel(Workspace ws) {
-    const int f = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ws.n_squares[f] || i >= MAXQ) return;
-    CandRec* out = ws.cand_recs + ((size_t)f * MAXQ + i) * MAXT;
-    const int r = ws.crop_of[(size_t)f * MAXQ + i];
-    unsigned long long best = ~0ull;
-    if (r >= 0) best = ws.best_crop[r];
-    if (best == ~0ull) {  // no quad in the crop: no candidate for this square (opencvar.cpp:704)
-        for (int j = 0; j < ws.n_templates; j++) out[j].valid = 0;
-        return;
-    }
-    const Roi roi = ws.rois_crop[r];
-    const QuadRec q = ws.quads_crop[(unsigned)(best & 0xffffffffu)];
-    float pat[8], pts[8];
-    for (int k = 0; k < 8; k++) {
-        pat[k] = (float)q.pt[k];
-        pts[k] = ws.squares[((size_t)f * MAXQ + i) * 8 + k];
-    }
-    const uint8_t* crop = ws.gray + (size_t)roi.frame * ws.W * ws.H + (size_t)roi.y0 * ws.W + roi.x0;
-    for (int j = 0; j < ws.n_templates; j++) {
-        const TemplateRec t = ws.templates[j];
-        const long long bit = read_code(crop, roi.w, roi.h, ws.W, pat, t.width, t.height);
-        const int orient = match_orient(bit, t);
-        if (orient == 4) rot_square(pts, 2);
-        else if (orient == 2) rot_square(pts, 4);
-        CandRec c;
-        c.valid = 1;
-        c.orient = orient;
-        c.bit = bit;
-        for (int k = 0; k < 8; k++) {
-            c.square[k] = pts[k];
-            c.patPoint[k] = pat[k];
+// Two phases per chunk of 32 frame-pass quads, one workgroup per frame.  Phase 1, one lane per (quad, template): the
+// inverse homography (8x8 solve in double; the destination quad is (tw+2) x (th+2), so it depends on the template) into
+// LDS.  Phase 2, one wave per quad and one lane per code cell: lane L samples the cell whose bit is bit L of the code --
+// acArray2DToBit packs row-major, columns right to left, first cell in the most significant bit (acmath.cpp:546-554) --
+// so the code is the ballot of the thresholded samples.  (One lane per quad walked ~77 dependent samples per quad;
+// one wave per quad for everything repeats the solve 64 times over.)
+constexpr int DECODE_CHUNK = 32;
+
+// (register budget of 4 waves per SIMD = 128 VGPRs and LDS sized by the actual template count: with several contexts in
+// flight the binarise kernels fill the SIMDs, and a workgroup that needs more waits until most of them have drained)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void decode_kernel(Workspace ws) {
+    extern __shared__ double sM_dyn[];   // [DECODE_CHUNK][n_templates][9]
+    __shared__ int s_roi[DECODE_CHUNK];        // crop ROI of the chunk's quad, -1: no quad in its crop
+    __shared__ unsigned s_slot[DECODE_CHUNK];  // quads_crop slot of the crop's quad
+    const int f = blockIdx.x;
+    const int tid = threadIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int T = ws.n_templates;
+    int nsq = ws.n_squares[f];
+    nsq = nsq < MAXQ ? nsq : MAXQ;
+    for (int base = 0; base < nsq; base += DECODE_CHUNK) {
+        const int cnt = nsq - base < DECODE_CHUNK ? nsq - base : DECODE_CHUNK;
+        if (tid < cnt) {
+            const int r = ws.crop_of[(size_t)f * MAXQ + base + tid];
+            unsigned long long best = ~0ull;
+            if (r >= 0) best = ws.best_crop[r];
+            s_roi[tid] = best == ~0ull ? -1 : r;
+            s_slot[tid] = (unsigned)(best & 0xffffffffu);
         }
-        out[j] = c;
+        __syncthreads();
+        for (int pair = tid; pair < cnt * T; pair += blockDim.x) {
+            const int qi = pair / T, j = pair - qi * T;
+            if (s_roi[qi] < 0) continue;
+            const QuadRec q = ws.quads_crop[s_slot[qi]];
+            float pat[8], m32[9];
+            for (int k = 0; k < 8; k++) pat[k] = (float)q.pt[k];
+            const TemplateRec t = ws.templates[j];
+            if (!perspective_from_quad(pat, t.width + 2, t.height + 2, m32))
+                for (int k = 0; k < 9; k++) m32[k] = 0.f;
+            double M[9];
+            invert_map(m32, M);
+            for (int k = 0; k < 9; k++) sM_dyn[(qi * T + j) * 9 + k] = M[k];
+        }
+        __syncthreads();
+        for (int qi = wave; qi < cnt; qi += 4) {
+            const int i = base + qi;
+            CandRec* out = ws.cand_recs + ((size_t)f * MAXQ + i) * MAXT;
+            const int r = s_roi[qi];
+            if (r < 0) {  // no quad in the crop: no candidate for this square (opencvar.cpp:704)
+                if (lane < T) out[lane].valid = 0;
+                continue;
+            }
+            const Roi roi = ws.rois_crop[r];
+            const QuadRec q = ws.quads_crop[s_slot[qi]];
+            float pat[8], pts[8];
+            for (int k = 0; k < 8; k++) {
+                pat[k] = (float)q.pt[k];
+                pts[k] = ws.squares[((size_t)f * MAXQ + i) * 8 + k];
+            }
+            const uint8_t* crop = ws.gray + (size_t)roi.frame * ws.W * ws.H + (size_t)roi.y0 * ws.W + roi.x0;
+            for (int j = 0; j < T; j++) {   // in order: the orient 2/4 corner rotation leaks into the next template (D4)
+                const TemplateRec t = ws.templates[j];
+                double M[9];
+                for (int k = 0; k < 9; k++) M[k] = sM_dyn[(qi * T + j) * 9 + k];
+                const int n = t.width * t.height;     // <= 64 (ocvar_hip_set_templates)
+                bool v = false;
+                if (lane < n) {
+                    const int p = n - 1 - lane;       // position in acArray2DToBit's scan: row p / tw, column tw-1 - p % tw
+                    const int ci = p / t.width, cj = t.width - 1 - p % t.width;
+                    int cx, cy;
+                    if (code_cell(ci * t.width + cj, t.width, t.height, &cx, &cy))
+                        v = warp_sample(crop, roi.w, roi.h, ws.W, M, cx + 1, cy + 1) > 100;
+                }
+                const long long bit = (long long)__ballot(v);
+                const int orient = match_orient(bit, t);
+                if (orient == 4) rot_square(pts, 2);
+                else if (orient == 2) rot_square(pts, 4);
+                if (lane == 0) {
+                    CandRec c;
+                    c.valid = 1;
+                    c.orient = orient;
+                    c.bit = bit;
+                    for (int k = 0; k < 8; k++) {
+                        c.square[k] = pts[k];
+                        c.patPoint[k] = pat[k];
+                    }
+                    out[j] = c;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -61,31 +115,67 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
     __shared__ int s_nout;
     const int f = blockIdx.x;
     const int T = ws.n_templates;
-    if (threadIdx.x == 0) {
-        const int nsq = ws.n_squares[f];
-        int n = 0;
+    const int lane = threadIdx.x;   // one wave per frame
+    // candidates in the reference's order (square-major, template-minor), compacted 64 slots at a time
+    int n = 0;
+    {
+        int nsq = ws.n_squares[f];
+        nsq = nsq < MAXQ ? nsq : MAXQ;
+        const int slots = nsq * T;
         bool overflow = false;
-        for (int i = 0; i < nsq && i < MAXQ; i++)
-            for (int j = 0; j < T; j++) {
+        for (int base = 0; base < slots; base += 64) {
+            const int s = base + lane;
+            const int i = s / T, j = s - i * T;
+            int orient = 0;
+            bool valid = false;
+            if (s < slots) {
                 const CandRec* c = ws.cand_recs + ((size_t)f * MAXQ + i) * MAXT + j;
-                if (!c->valid) continue;
-                if (n >= MAXC) {
-                    overflow = true;
-                    continue;
-                }
-                s_mid[n] = i;
-                s_tid[n] = j;
-                s_score[n] = c->orient ? 1 : 0;
-                n++;
+                valid = c->valid != 0;
+                orient = c->orient;
             }
-        if (overflow) atomicOr(ws.counters + CNT_ERR, ERR_QUAD_OVERFLOW);
-        // opencvar.cpp:780-792
-        for (int a = 0; a < n; a++)
-            for (int b = 0; b < a; b++)
-                if (s_mid[a] == s_mid[b] || s_tid[a] == s_tid[b]) {
-                    if (s_score[a] > s_score[b]) s_mid[b] = -1;
-                    else s_mid[a] = -1;
+            const unsigned long long m = __ballot(valid);
+            const int at = n + __popcll(m & ((1ull << lane) - 1ull));
+            if (valid) {
+                if (at < MAXC) {
+                    s_mid[at] = i;
+                    s_tid[at] = j;
+                    s_score[at] = orient ? 1 : 0;
+                } else {
+                    overflow = true;
                 }
+            }
+            n += __popcll(m);
+        }
+        if (__ballot(overflow) && lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_QUAD_OVERFLOW);
+        n = n < MAXC ? n : MAXC;
+    }
+    __syncthreads();
+    // opencvar.cpp:780-792, the order-dependent `||` elimination: for a, for b < a: if same square or same template, the
+    // lower score (ties: a) gets markerId -1.  The inner loop is replayed 64 values of b at a time: until a itself is
+    // eliminated -- at the first b it loses to -- every matching b with a lower score is eliminated; from there on
+    // markerId[a] is -1, which still "matches" eliminated b's (a no-op) and same-template b's.  Same result as the
+    // sequential loop, entry for entry.
+    for (int a = 1; a < n; a++) {
+        const int ma = s_mid[a], ta = s_tid[a];
+        const int sa = s_score[a];
+        bool dead = false;   // wave-uniform: markerId[a] has become -1 inside this inner loop
+        for (int base = 0; base < a; base += 64) {
+            const int b = base + lane;
+            const bool in = b < a;
+            const int mb = in ? s_mid[b] : -2, tb = in ? s_tid[b] : -2, sb = in ? (int)s_score[b] : 0;
+            const bool pre = in && (ma == mb || ta == tb);        // match while markerId[a] is still ma
+            const bool post = in && (mb == -1 || ta == tb);       // match once markerId[a] is -1
+            const bool wins = sa > sb;
+            unsigned long long lose = dead ? 0ull : __ballot(pre && !wins);
+            const int bstar = lose ? __ffsll((long long)lose) - 1 : 64;
+            const bool kill = wins && (dead ? post : (lane < bstar ? pre : (lane > bstar ? post : false)));
+            if (kill) s_mid[b] = -1;
+            dead = dead || lose != 0;
+        }
+        if (dead && lane == 0) s_mid[a] = -1;
+        __syncthreads();
+    }
+    if (lane == 0) {
         int nout = 0, total = 0;
         const int nr = ws.n_reserve[f];
         for (int k = 0; k < nr; k++) {  // tracked markers first (662-668)
@@ -126,7 +216,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
 }
 
 void launch_decode(const Workspace& ws, hipStream_t stream) {
-    if (ws.n_frames > 0) hipLaunchKernelGGL(decode_kernel, dim3((MAXQ + 63) / 64, ws.n_frames), dim3(64), 0, stream, ws);
+    if (ws.n_frames > 0)
+        hipLaunchKernelGGL(decode_kernel, dim3(ws.n_frames), dim3(256), (size_t)DECODE_CHUNK * ws.n_templates * 9 * sizeof(double), stream, ws);
 }
 void launch_finalise(const Workspace& ws, hipStream_t stream) {
     if (ws.n_frames > 0) hipLaunchKernelGGL(finalise_kernel, dim3(ws.n_frames), dim3(64), 0, stream, ws);
