@@ -230,7 +230,7 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     if (w.long_blocks < 1 || w.long_blocks > w.max_long_blocks) w.long_blocks = w.max_long_blocks;
     // the fixed grids of the work-queue kernels shrink with the batch: a one-frame call does not launch (and wait out) the
     // thousands of workgroups that keep a 2048-frame batch busy
-    w.short_blocks = n_frames >= 128 ? 1024 : (n_frames * 8 < 16 ? 16 : n_frames * 8);
+    w.short_blocks = std::getenv("OCVAR_SHORT_BLOCKS") ? std::atoi(std::getenv("OCVAR_SHORT_BLOCKS")) : (n_frames >= 128 ? 1024 : (n_frames * 8 < 16 ? 16 : n_frames * 8));
     w.crop_blocks = n_frames >= 128 ? 2048 : (n_frames * 16 < 32 ? 32 : n_frames * 16);
     w.frame_strips = (w.sw + MARCH_STRIP - 1) / MARCH_STRIP;
     {   // rows per binarise work unit: even, chunks of equal size.  Every chunk re-reads ~12 halo rows, so chunks are as

@@ -396,13 +396,12 @@ __device__ __forceinline__ bool wave_finish_packed(const Workspace& ws, const St
 // Tier 1, one lane per start, mask bytes read from global memory (one memory latency per step, 64 starts per wave in
 // flight).  It sees every plausible start, and most of them drop out within a few steps (noise, staircase false
 // starts).  Returns the route: 0 = dead, 1 = tier 2, 2 = straight to tier 3.
-template <bool CROP, int TIER>
-__device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand c, int* slab_npts) {
-    static_assert(TIER == 1, "tier 2 is follow_mid_kernel");
+template <bool CROP>
+__device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand c) {
     const int BUDGET = SHORT_STEPS;
     const PlaneRef pl = plane_of<CROP>(ws, c.roi);
     if (c.pos <= 0 || c.pos >= pl.plane) return false;
-    if (TIER == 1) {
+    {
         // tier 1 only decides where a start goes: a look behind (outer starts), then SHORT_STEPS store-free steps.
         // Dead (not the border's first position, isolated pixel, fewer than 4 corner points): dropped.  Closed within the
         // budget or still running: tier 2, which follows again with point storage -- or straight to the wave tier when
@@ -447,94 +446,109 @@ __device__ int follow_overflow(const Workspace& ws, const StartCand c, const Pla
     return 0;
 }
 
-template <bool CROP, int TIER>
+// A single global counter sustains only ~90 atomics per microsecond chip-wide (measured in round 1 on the start lists).
+// One ticket per 64 starts plus one list append per 64-start batch was therefore this kernel's whole duration (5.7 M crop
+// starts per 2048 frames = 89 k tickets = 1 ms).  A wave now takes T1_TICKET starts per ticket and collects the starts it
+// routes on in LDS, appending them T1_OUT at a time with one atomic.
+constexpr int T1_TICKET = 512;
+constexpr int T1_OUT = 128;
+
+template <bool CROP>
 __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
-    const StartCand* cands = TIER == 1 ? (CROP ? ws.cands_crop : ws.cands_frame) : (CROP ? ws.mid_crop : ws.mid_frame);
-    StartCand* longs = TIER == 1 ? (CROP ? ws.mid_crop : ws.mid_frame) : (CROP ? ws.long_crop : ws.long_frame);
-    int n = ws.counters[TIER == 1 ? (CROP ? CNT_CROP_CANDS : CNT_FRAME_CANDS) : (CROP ? CNT_MID_C : CNT_MID_F)];
-    const int cap = TIER == 1 ? (CROP ? ws.cap_crop_cands : ws.cap_frame_cands) : ws.cap_long;
+    const StartCand* cands = CROP ? ws.cands_crop : ws.cands_frame;
+    int n = ws.counters[CROP ? CNT_CROP_CANDS : CNT_FRAME_CANDS];
+    const int cap = CROP ? ws.cap_crop_cands : ws.cap_frame_cands;
     if (n > cap) n = cap;
-    int* ticket = ws.counters + (TIER == 1 ? (CROP ? CNT_TICKET_C : CNT_TICKET_F) : (CROP ? CNT_TICKET_MC : CNT_TICKET_MF));
-    int* n_long = ws.counters + (TIER == 1 ? (CROP ? CNT_MID_C : CNT_MID_F) : (CROP ? CNT_LONG_C : CNT_LONG_F));
+    int* ticket = ws.counters + (CROP ? CNT_TICKET_C : CNT_TICKET_F);
     const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6));
-    // Tier 1 sees every plausible start, and most of them are dead after a handful of steps (a staircase pixel of a
-    // slanted edge, image noise) while a few run the whole budget: a wave of 64 fresh starts would spend the full budget
-    // with almost all lanes idle.  So fresh starts first get PRE_STEPS steps each, the survivors are queued per wave in
-    // LDS, and the full-budget follow only ever runs on (nearly) full waves of survivors.
-    __shared__ StartCand wqueue[TIER == 1 ? 4 : 1][TIER == 1 ? 128 : 1];
-    int queued = 0;      // wave-uniform
-    bool more = true;    // tickets left
-    // every iteration consumes a ticket of 64 starts or up to 64 queued survivors: more iterations than that account for
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // Tier 1 sees every plausible start, and most of them are dead at once (run_has_earlier_pixel) or after a handful of
+    // steps (a staircase pixel of a slanted edge, image noise) while a few run the whole budget: a wave of 64 fresh starts
+    // would spend the full budget with almost all lanes idle.  So fresh starts first get the run test and PRE_STEPS steps
+    // each, the survivors are queued per wave in LDS, and the full-budget follow only ever runs on (nearly) full waves of
+    // survivors.
+    __shared__ StartCand wqueue[4][128];
+    __shared__ StartCand obuf[4][3][T1_OUT];   // routed starts waiting for their append: to tier 2, to tier 3, to tier 2's "first" list
+    int o_n0 = 0, o_n1 = 0, o_n2 = 0;          // wave-uniform fill levels
+    auto append = [&](int t, int& o_n) {       // one atomic for everything collected for target t
+        if (o_n == 0) return;
+        StartCand* list = t == 0 ? (CROP ? ws.mid_crop : ws.mid_frame) : t == 1 ? (CROP ? ws.long_crop : ws.long_frame) : ws.mid_first_crop;
+        int* count = ws.counters + (t == 0 ? (CROP ? CNT_MID_C : CNT_MID_F) : t == 1 ? (CROP ? CNT_LONG_C : CNT_LONG_F) : CNT_MID_C_FIRST);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        int qbase = 0;
+        if (lane == 0) qbase = atomicAdd(count, o_n);
+        qbase = uni(qbase);
+        for (int i = lane; i < o_n; i += 64) {
+            if (qbase + i < ws.cap_long) list[qbase + i] = obuf[wave][t][i];
+            else atomicOr(ws.counters + CNT_ERR, ERR_CAND_OVERFLOW);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        o_n = 0;
+    };
+    auto collect = [&](int t, int& o_n, bool mine, const StartCand& c) {
+        const unsigned long long mask = __ballot(mine);
+        if (!mask) return;
+        const int cnt = __popcll(mask);
+        if (o_n + cnt > T1_OUT) append(t, o_n);
+        if (mine) obuf[wave][t][o_n + __popcll(mask & below)] = c;
+        o_n += cnt;
+    };
+    int queued = 0;                // wave-uniform
+    int tk_next = 0, tk_end = 0;   // wave-uniform: the part of the list this wave has taken a ticket for
+    bool more = true;              // tickets left
+    // every iteration consumes 64 starts of a ticket or up to 64 queued survivors: more iterations than that account for
     // means the loop's control flow is broken (see ticket_lane()); report instead of spinning
     for (int guard = 2 * (n / 64 + 2) + 2;; guard--) {
         if (guard < 0) {
             if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TICKET_RUNAWAY);
             break;
         }
-        StartCand c;
-        c.roi = 0; c.pos = 0; c.is_hole = 0;
-        int route = 0, slab_npts = 0;
-        if (TIER == 1) {
-            while (more && queued < 64) {
+        while (more && queued < 64) {
+            if (tk_next >= tk_end) {
                 int base = 0;
-                if (ticket_lane() == 0) base = atomicAdd(ticket, 64);
+                if (ticket_lane() == 0) base = atomicAdd(ticket, T1_TICKET);
                 base = uni(base);
                 if (base >= n) {
                     more = false;
                     break;
                 }
-                const int idx = base + lane;
-                bool alive = false;
-                StartCand cc;
-                cc.roi = 0; cc.pos = 0; cc.is_hole = 0;
-                if (idx < n) {
-                    cc = cands[idx];
-                    const PlaneRef pl = plane_of<CROP>(ws, cc.roi);
-                    if (cc.pos > 0 && cc.pos < pl.plane)
-                        alive = trace_flat(pl.nbr, pl.ns, pl.plane, cc.pos, cc.is_hole, nullptr, 0, PRE_STEPS).status == TRACE_OVERRUN;
-                }
-                const unsigned long long mask = __ballot(alive);
-                if (alive) wqueue[wave][queued + __popcll(mask & ((1ull << lane) - 1ull))] = cc;
-                queued += __popcll(mask);
+                tk_next = base;
+                tk_end = base + T1_TICKET < n ? base + T1_TICKET : n;
             }
-            if (queued == 0) break;
-            const int take = queued < 64 ? queued : 64;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            if (lane < take) {
-                c = wqueue[wave][queued - take + lane];
-                route = follow_short<CROP, TIER>(ws, c, &slab_npts);
+            const int idx = tk_next + lane;
+            tk_next += 64;
+            bool alive = false;
+            StartCand cc;
+            cc.roi = 0; cc.pos = 0; cc.is_hole = 0;
+            if (idx < tk_end) {
+                cc = cands[idx];
+                const PlaneRef pl = plane_of<CROP>(ws, cc.roi);
+                if (cc.pos > 0 && cc.pos < pl.plane && !run_has_earlier_pixel(pl.nbr, pl.ns, cc.pos, cc.is_hole, 8))
+                    alive = trace_flat(pl.nbr, pl.ns, pl.plane, cc.pos, cc.is_hole, nullptr, 0, PRE_STEPS).status == TRACE_OVERRUN;
             }
-            queued -= take;
-        } else {
-            int base = 0;
-            if (ticket_lane() == 0) base = atomicAdd(ticket, 64);
-            base = uni(base);
-            if (base >= n) break;
-            const int idx = base + lane;
-            if (idx < n) {
-                c = cands[idx];
-                route = follow_short<CROP, TIER>(ws, c, &slab_npts);
-            }
+            const unsigned long long mask = __ballot(alive);
+            if (alive) wqueue[wave][queued + __popcll(mask & below)] = cc;
+            queued += __popcll(mask);
         }
-#pragma unroll
-        for (int target = 1; target <= (TIER == 1 ? (CROP ? 3 : 2) : 1); target++) {
-            StartCand* list = (TIER == 1 && target == 2) ? (CROP ? ws.long_crop : ws.long_frame) : (target == 3 ? ws.mid_first_crop : longs);
-            int* count = (TIER == 1 && target == 2) ? ws.counters + (CROP ? CNT_LONG_C : CNT_LONG_F) : (target == 3 ? ws.counters + CNT_MID_C_FIRST : n_long);
-            const bool queue = route == target;
-            const unsigned long long mask = __ballot(queue);
-            if (!mask) continue;
-            int qbase = 0;
-            const int leader = __ffsll((long long)mask) - 1;
-            if (lane == leader) qbase = atomicAdd(count, __popcll(mask));
-            qbase = __builtin_amdgcn_readlane(qbase, leader);
-            if (queue) {
-                const int slot = qbase + __popcll(mask & ((1ull << lane) - 1ull));
-                if (slot < ws.cap_long) list[slot] = c;
-                else atomicOr(ws.counters + CNT_ERR, ERR_CAND_OVERFLOW);
-            }
+        if (queued == 0) break;
+        const int take = queued < 64 ? queued : 64;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        StartCand c;
+        c.roi = 0; c.pos = 0; c.is_hole = 0;
+        int route = 0;
+        if (lane < take) {
+            c = wqueue[wave][queued - take + lane];
+            route = follow_short<CROP>(ws, c);
         }
+        queued -= take;
+        collect(0, o_n0, route == 1, c);
+        collect(1, o_n1, route == 2, c);
+        if (CROP) collect(2, o_n2, route == 3, c);
     }
+    append(0, o_n0);
+    append(1, o_n1);
+    if (CROP) append(2, o_n2);
 }
 
 // ---- Tier 2: one lane per surviving border, 64 independent walks per wave, lanes refilled as they finish -------------
@@ -589,7 +603,8 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
             if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TICKET_RUNAWAY);
             break;
         }
-        // hand idle lanes the next starts of the list (one ticket fetch for all of them)
+        // hand idle lanes the next starts of the list (one ticket fetch for all of them; taking list entries in bulk per wave
+        // instead was slower: lanes wait for the next round whenever the wave's range runs out, and the ranges unbalance the tail)
         const unsigned long long idle = __ballot(!have);
         if (more && idle) {
             const int cnt = __popcll(idle);
@@ -1002,10 +1017,10 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
 }
 
 void launch_follow_frames(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL((follow_kernel<false, 1>), dim3(ws.short_blocks), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL(follow_kernel<false>, dim3(ws.short_blocks), dim3(256), 0, stream, ws);
 }
 void launch_follow_crops(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL((follow_kernel<true, 1>), dim3(ws.short_blocks), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL(follow_kernel<true>, dim3(ws.short_blocks), dim3(256), 0, stream, ws);
 }
 void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_mid_kernel<false>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws);

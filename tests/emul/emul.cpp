@@ -9,6 +9,8 @@
 
 using namespace ocvar;
 static int g_back = 32;
+static int g_run_filter = 1;   // follow.hip tier 1: run_has_earlier_pixel before any step
+extern "C" void emul_set_run_filter(int v) { g_run_filter = v; }
 static int g_run = 1;
 static int g_lean = 0;
 extern "C" void emul_set_lean(int v) { g_lean = v; }
@@ -51,6 +53,7 @@ extern "C" int emul_find_contours(const uint8_t* bin, int w, int h, int* pts, in
             bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1) && !(b(x + 1, y) && b(x + 2, y - 1));
             bool hole = !c && b(x - 1, y) && b(x, y - 1) && (b(x + 1, y) || b(x + 1, y - 1));
             if (!outer && !hole) continue;
+            if (g_run_filter && run_has_earlier_pixel(nbr.data(), w, y * w + x, hole ? 1 : 0, 8)) continue;
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), w, w * h, y * w + x, 0, g_back)) { g_back_drops++; continue; }
             TraceStats st;
             if (g_lean) {
@@ -127,6 +130,7 @@ extern "C" int emul_find_squares_bin(const uint8_t* bin, int sw, int sh, int img
             bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1) && !(b(x + 1, y) && b(x + 2, y - 1));
             bool hole = !c && b(x - 1, y) && b(x, y - 1) && (b(x + 1, y) || b(x + 1, y - 1));
             if (!outer && !hole) continue;
+            if (g_run_filter && run_has_earlier_pixel(nbr.data(), sw, y * sw + x, hole ? 1 : 0, 8)) continue;
             if (outer && g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, 0, g_back)) { g_back_drops++; continue; }
             st_[0]++;
             if (g_lean) {   // the tier-2/3 flow: store while following, statistics from the stored points
