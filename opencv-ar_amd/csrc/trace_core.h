@@ -335,14 +335,16 @@ OCVAR_HD void flat_step_t(FlatWalk& w, const uint8_t* nbr, int ns, int plane, in
     const int t = __builtin_ctz(((w.m * 0x101u) >> from) & 0xffu);   // zero neighbours passed before the next border pixel
     const int e = (from + t) & 7;                                     // exit direction
     const unsigned passed = ((((1u << t) - 1u) * 0x101u) << from) >> 8;   // 8-bit rotate of t ones to position `from`
-    const bool budget = BUDGET && w.step >= max_steps;
-    const bool nf = !budget && (((passed & 0x10u) != 0 && w.idx < cpos) || ((passed & 1u) != 0 && w.idx + 1 < cpos));
+    // (bitwise & and | on purpose: with && and || the compiler turns these predicates into nested divergent branches --
+    // EXEC save/restore and a scalar branch per condition and step)
+    const bool budget = BUDGET & (w.step >= max_steps);
+    const bool nf = !budget & ((((passed & 0x10u) != 0) & (w.idx < cpos)) | (((passed & 1u) != 0) & (w.idx + 1 < cpos)));
     const int dx = step_dx(e), dy = step_dy(e);
     const int nidx = w.idx + mul_small(dy, ns) + dx;
-    const bool closes = !budget && !nf && nidx == w.i0 && w.idx == w.i1;
-    const bool oob = !budget && !nf && !closes && (unsigned)nidx >= (unsigned)plane;
-    const bool go = !(budget || nf || closes || oob);
-    const bool emit = e != w.prev_s && (go || closes);   // CHAIN_APPROX_SIMPLE: a point wherever the direction changes
+    const bool closes = !budget & !nf & (nidx == w.i0) & (w.idx == w.i1);
+    const bool oob = !budget & !nf & !closes & ((unsigned)nidx >= (unsigned)plane);
+    const bool go = !(budget | nf | closes | oob);
+    const bool emit = (e != w.prev_s) & (go | closes);   // CHAIN_APPROX_SIMPLE: a point wherever the direction changes
     const int lx = go ? w.x + dx : w.x, ly = go ? w.y + dy : w.y;
     const unsigned m4 = nbr[nbr_addr(lx, ly, ns)];
     store(emit, w.x, w.y);
