@@ -409,7 +409,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     flush();
 }
 
-__global__ __launch_bounds__(256) void binarise_frames_kernel(Workspace ws, const uint8_t* bgr, int row_stride, size_t frame_stride) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void binarise_frames_kernel(Workspace ws, const uint8_t* bgr, int row_stride, size_t frame_stride) {
     __shared__ unsigned stage[4][MARCH_STAGE];
     __shared__ __attribute__((aligned(16))) unsigned rowbuf[4][8 * 64];
     __shared__ uint4 tab[128];
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void grey_writeback_kernel(Workspace ws, uint8
     }
 }
 
-__global__ __launch_bounds__(256) void binarise_crops_kernel(Workspace ws) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void binarise_crops_kernel(Workspace ws) {
     __shared__ unsigned stage[4][MARCH_STAGE];
     __shared__ __attribute__((aligned(16))) unsigned rowbuf[4][8 * 64];
     __shared__ uint4 tab[128];
