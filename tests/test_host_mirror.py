@@ -203,6 +203,36 @@ def test_geometry_helpers_follow_the_reference(host):
     assert np.abs(m_host - m_ref).max() <= 1e-4 * max(1.0, np.abs(m_ref).max())
 
 
+class _CvMat(C.Structure):   # include/shim/opencv/cv.h (OpenCV's layout): type, step, refcount, hdr_refcount, data, rows, cols
+    _fields_ = [("type", C.c_int), ("step", C.c_int), ("refcount", C.c_void_p), ("hdr_refcount", C.c_int), ("data", C.c_void_p),
+                ("rows", C.c_int), ("cols", C.c_int)]
+
+
+def test_find_camera_solves_the_marker_rectangle_and_refuses_anything_else(host, capfd):
+    """cvarFindCamera (opencvar.cpp:261-278) is only ever handed cvarSquareInit's rectangle (229-245, 529-536): that is what
+    the library solves (distortion coefficients included); other object points are refused loudly, not mis-solved."""
+    cam = H.oracle_camera(640, 480)
+    cam.distCoeffs[0], cam.distCoeffs[1] = -0.1, 0.03
+    obj, img = np.zeros(12), np.array([200, 150, 330, 160, 320, 290, 190, 280], np.float64)
+    mo, mi = _CvMat(), _CvMat()
+    mo.data, mo.rows, mo.cols = obj.ctypes.data, 4, 3
+    mi.data, mi.rows, mi.cols = img.ctypes.data, 4, 2
+    host.cvarSquareInit.argtypes = [C.c_void_p, C.c_double]
+    host.cvarSquareInit(C.byref(mo), 0.75)
+    assert obj.tolist() == [-0.75, -1, 0, 0.75, -1, 0, 0.75, 1, 0, -0.75, 1, 0]
+    got, ref = np.zeros(16), np.zeros(16)
+    host.cvarFindCamera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    host.cvarFindCamera(C.byref(cam), C.byref(mo), C.byref(mi), P(got))
+    H.oracle().orc_square_to_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    H.oracle().orc_square_to_matrix(P(img.astype(np.float32)), C.byref(cam), 0.75, P(ref))
+    assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    obj[4] = -0.5   # no longer the rectangle
+    untouched = np.full(16, 7.0)
+    host.cvarFindCamera(C.byref(cam), C.byref(mo), C.byref(mi), P(untouched))
+    assert (untouched == 7.0).all()
+    assert "not the marker rectangle" in capfd.readouterr().err
+
+
 @pytest.mark.gpu
 def test_artest_headless_matches_oracle():
     exe = os.path.join(H.PKG, "bin", "artest_headless")
