@@ -54,13 +54,21 @@ enum {
     OCVAR_E_CAPACITY = -4     /* a device work list overflowed (frame too cluttered for the configured limits) */
 };
 
-enum { OCVAR_MAX_TEMPLATES = 16, OCVAR_MAX_QUADS = 256, OCVAR_MAX_MARKERS = 64 };
+enum { OCVAR_MAX_TEMPLATES = 16, OCVAR_MAX_QUADS = 256, OCVAR_MAX_MARKERS = 64,
+       OCVAR_MAX_QUADS_EX = 1792 /* most squares per frame a context can be created for (ocvar_hip_create_ex) */ };
 
 /* Creates a context on `device` with workspace for batches of up to max_batch frames of up to
  * max_width x max_height pixels. */
 int ocvar_hip_create(OcvarHip** ctx, int device, int max_width, int max_height, int max_batch);
+/* Same with room for max_quads (1 .. OCVAR_MAX_QUADS_EX) frame-pass squares per frame instead of OCVAR_MAX_QUADS: the
+ * reference's square list is unbounded (opencvar.cpp:187-214); a caller that gets OCVAR_E_CAPACITY with flag 4 (squares)
+ * repeats the frame on such a context (the host mirror of cvarArMultRegistration / cvarFindSquares does). */
+int ocvar_hip_create_ex(OcvarHip** ctx, int device, int max_width, int max_height, int max_batch, int max_quads);
 void ocvar_hip_destroy(OcvarHip* ctx);
 const char* ocvar_hip_last_error(const OcvarHip* ctx);
+/* Flag word of the last call that failed with OCVAR_E_CAPACITY: 1 start lists, 2 point pool, 4 squares / candidates per
+ * frame, 8 trace overrun, 16 crops, 32 crop tiles, 64 work-queue runaway, 128 markers per frame.  0 after a good call. */
+int ocvar_hip_capacity_flags(const OcvarHip* ctx);
 
 int ocvar_hip_set_templates(OcvarHip* ctx, const OcvarTemplate* templates, int n);
 int ocvar_hip_set_camera(OcvarHip* ctx, const OcvarCamera* camera);

@@ -21,7 +21,7 @@ MAX_TEMPLATES, MAX_QUADS, MAX_MARKERS = 16, 256, 64
 
 # every symbol include/ocvar_hip.h declares
 HIP_SYMBOLS = [
-    "ocvar_hip_create", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
+    "ocvar_hip_create", "ocvar_hip_create_ex", "ocvar_hip_capacity_flags", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
     "ocvar_hip_detect_device", "ocvar_hip_enqueue", "ocvar_hip_collect", "ocvar_hip_detect_host", "ocvar_hip_find_squares",
     "ocvar_hip_debug_gray", "ocvar_hip_debug_binary", "ocvar_hip_debug_frame_quads", "ocvar_hip_debug_candidates",
     "ocvar_hip_stage_ms", "ocvar_hip_counters", "ocvar_hip_results_to_device", "ocvar_hip_debug_calibrate",

@@ -39,6 +39,7 @@ struct OcvarHip {
     int* h_counters = nullptr;       // pinned
     bool pending = false;
     bool have_templates = false, have_camera = false;
+    int capacity_flags = 0;   // flag word of the last batch that failed with OCVAR_E_CAPACITY
     std::string err;
 };
 
@@ -61,7 +62,11 @@ static int dev_alloc(OcvarHip* c, T** p, size_t n) {
 }
 
 extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int max_height, int max_batch) {
-    if (!out || max_width < 16 || max_height < 16 || max_batch < 1) return OCVAR_E_ARG;
+    return ocvar_hip_create_ex(out, device, max_width, max_height, max_batch, OCVAR_MAX_QUADS);
+}
+
+extern "C" int ocvar_hip_create_ex(OcvarHip** out, int device, int max_width, int max_height, int max_batch, int max_quads) {
+    if (!out || max_width < 16 || max_height < 16 || max_batch < 1 || max_quads < 1 || max_quads > OCVAR_MAX_QUADS_EX) return OCVAR_E_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return OCVAR_E_NO_DEVICE;
@@ -90,13 +95,15 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     w.max_w = max_width;
     w.max_h = max_height;
     w.max_batch = max_batch;
+    w.maxq = max_quads;
+    w.maxc = max_quads;   // set with the templates (maxq * n_templates, at most what 64 KB of LDS hold)
     const size_t B = (size_t)max_batch, WH = (size_t)max_width * max_height;
     size_t per_frame_cands = WH / 16 < 16384 ? 16384 : WH / 16;
     w.cap_frame_cands = (int)std::min<size_t>(B * per_frame_cands, (size_t)1 << 30);
     w.cap_crop_cands = w.cap_frame_cands;
-    w.cap_crop_rois = (int)(B * MAXQ);
+    w.cap_crop_rois = (int)(B * max_quads);
     w.cap_crop_tiles = (int)std::min<size_t>(B * 4096, (size_t)1 << 30);
-    w.cap_crop_quads = (int)(B * MAXQ * 4);
+    w.cap_crop_quads = (int)(B * max_quads * 4);
     // only tier-2 borders with more corner points than a lane slab holds land here; the fixed part lets a small context take
     // a pathological frame (full-frame noise: thousands of long ragged borders)
     w.cap_pool_ints = (long long)B * (1 << 18) + (1 << 24);
@@ -120,16 +127,16 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
     if ((rc = dev_alloc(c, &w.mid_first_crop, (size_t)w.cap_long))) return rc;
     if ((rc = dev_alloc(c, &w.long_frame, (size_t)w.cap_long))) return rc;
     if ((rc = dev_alloc(c, &w.long_crop, (size_t)w.cap_long))) return rc;
-    if ((rc = dev_alloc(c, &w.quads_frame, B * MAXQ))) return rc;
+    if ((rc = dev_alloc(c, &w.quads_frame, B * max_quads))) return rc;
     if ((rc = dev_alloc(c, &w.n_quads_frame, B))) return rc;
-    if ((rc = dev_alloc(c, &w.squares, B * MAXQ * 8))) return rc;
+    if ((rc = dev_alloc(c, &w.squares, B * max_quads * 8))) return rc;
     if ((rc = dev_alloc(c, &w.n_squares, B))) return rc;
-    if ((rc = dev_alloc(c, &w.crop_of, B * MAXQ))) return rc;
+    if ((rc = dev_alloc(c, &w.crop_of, B * max_quads))) return rc;
     if ((rc = dev_alloc(c, &w.rois_crop, (size_t)w.cap_crop_rois))) return rc;
     if ((rc = dev_alloc(c, &w.tiles_crop, (size_t)w.cap_crop_tiles))) return rc;
     if ((rc = dev_alloc(c, &w.quads_crop, (size_t)w.cap_crop_quads))) return rc;
     if ((rc = dev_alloc(c, &w.best_crop, (size_t)w.cap_crop_rois))) return rc;
-    if ((rc = dev_alloc(c, &w.cand_recs, B * MAXQ * MAXT))) return rc;
+    if ((rc = dev_alloc(c, &w.cand_recs, B * max_quads * MAXT))) return rc;
     if ((rc = dev_alloc(c, &w.prev, B * MAXM))) return rc;
     if ((rc = dev_alloc(c, &w.n_prev, B))) return rc;
     if ((rc = dev_alloc(c, &w.reserve, B * MAXM))) return rc;
@@ -171,6 +178,7 @@ extern "C" void ocvar_hip_destroy(OcvarHip* c) {
 }
 
 extern "C" const char* ocvar_hip_last_error(const OcvarHip* c) { return c ? c->err.c_str() : "null context"; }
+extern "C" int ocvar_hip_capacity_flags(const OcvarHip* c) { return c ? c->capacity_flags : 0; }
 
 extern "C" int ocvar_hip_set_templates(OcvarHip* c, const OcvarTemplate* t, int n) {
     if (!c || !t || n < 1 || n > MAXT) return OCVAR_E_ARG;
@@ -179,6 +187,7 @@ extern "C" int ocvar_hip_set_templates(OcvarHip* c, const OcvarTemplate* t, int 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpy(c->ws.templates, t, n * sizeof(OcvarTemplate), hipMemcpyHostToDevice));
     c->ws.n_templates = n;
+    c->ws.maxc = std::min(c->ws.maxq * n, 7000);   // 9 bytes of LDS per candidate, 64 KB per workgroup
     c->have_templates = true;
     return OCVAR_OK;
 }
@@ -324,6 +333,7 @@ static int wait_impl(OcvarHip* c) {
     HIP_TRY(c, hipStreamSynchronize(c->last_stream));
     c->pending = false;
     const int e = c->h_counters[CNT_ERR];
+    c->capacity_flags = e;
     if (e) {
         char buf[160];
         std::snprintf(buf, sizeof buf, "device work list overflow / trace overrun, flags 0x%x (1 starts, 2 point pool, 4 quads, 8 overrun, 16 crops, 32 tiles, 64 ticket runaway, 128 markers)", e);
@@ -521,7 +531,7 @@ extern "C" int ocvar_hip_find_squares(OcvarHip* c, const uint8_t* h_gray, int wi
     if (rc) return rc;
     int n = 0;
     HIP_TRY(c, hipMemcpy(&n, c->ws.n_squares, sizeof(int), hipMemcpyDeviceToHost));
-    std::vector<float> sq((size_t)MAXQ * 8);
+    std::vector<float> sq((size_t)c->ws.maxq * 8);
     HIP_TRY(c, hipMemcpy(sq.data(), c->ws.squares, sq.size() * sizeof(float), hipMemcpyDeviceToHost));
     *n_quads = n;
     for (int i = 0; i < n && i < max_quads; i++)
@@ -555,10 +565,10 @@ extern "C" int ocvar_hip_debug_frame_quads(OcvarHip* c, int frame, int* quads, i
     HIP_TRY(c, hipSetDevice(c->device));
     int n = 0;
     HIP_TRY(c, hipMemcpy(&n, c->ws.n_squares + frame, sizeof(int), hipMemcpyDeviceToHost));
-    std::vector<float> sq((size_t)MAXQ * 8);
-    HIP_TRY(c, hipMemcpy(sq.data(), c->ws.squares + (size_t)frame * MAXQ * 8, sq.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<float> sq((size_t)OCVAR_MAX_QUADS * 8);   // the documented size of `quads`; contexts made for more squares report the first of them
+    HIP_TRY(c, hipMemcpy(sq.data(), c->ws.squares + (size_t)frame * c->ws.maxq * 8, sq.size() * sizeof(float), hipMemcpyDeviceToHost));
     *n_quads = n;
-    for (int i = 0; i < n && i < MAXQ; i++)
+    for (int i = 0; i < n && i < OCVAR_MAX_QUADS; i++)
         for (int k = 0; k < 8; k++) quads[8 * i + k] = (int)sq[8 * (size_t)i + k];
     return OCVAR_OK;
 }
@@ -568,9 +578,9 @@ extern "C" int ocvar_hip_debug_candidates(OcvarHip* c, int frame, OcvarCandidate
     HIP_TRY(c, hipSetDevice(c->device));
     int nsq = 0;
     HIP_TRY(c, hipMemcpy(&nsq, c->ws.n_squares + frame, sizeof(int), hipMemcpyDeviceToHost));
-    if (nsq > MAXQ) nsq = MAXQ;
-    std::vector<CandRec> recs((size_t)MAXQ * MAXT);
-    HIP_TRY(c, hipMemcpy(recs.data(), c->ws.cand_recs + (size_t)frame * MAXQ * MAXT, recs.size() * sizeof(CandRec), hipMemcpyDeviceToHost));
+    if (nsq > c->ws.maxq) nsq = c->ws.maxq;
+    std::vector<CandRec> recs((size_t)c->ws.maxq * MAXT);
+    HIP_TRY(c, hipMemcpy(recs.data(), c->ws.cand_recs + (size_t)frame * c->ws.maxq * MAXT, recs.size() * sizeof(CandRec), hipMemcpyDeviceToHost));
     int n = 0;
     for (int i = 0; i < nsq; i++)
         for (int j = 0; j < c->ws.n_templates; j++) {

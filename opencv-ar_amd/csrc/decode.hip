@@ -30,11 +30,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int T = ws.n_templates;
     int nsq = ws.n_squares[f];
-    nsq = nsq < MAXQ ? nsq : MAXQ;
+    nsq = nsq < ws.maxq ? nsq : ws.maxq;
     for (int base = 0; base < nsq; base += DECODE_CHUNK) {
         const int cnt = nsq - base < DECODE_CHUNK ? nsq - base : DECODE_CHUNK;
         if (tid < cnt) {
-            const int r = ws.crop_of[(size_t)f * MAXQ + base + tid];
+            const int r = ws.crop_of[(size_t)f * ws.maxq + base + tid];
             unsigned long long best = ~0ull;
             if (r >= 0) best = ws.best_crop[r];
             s_roi[tid] = best == ~0ull ? -1 : r;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         __syncthreads();
         for (int qi = wave; qi < cnt; qi += 4) {
             const int i = base + qi;
-            CandRec* out = ws.cand_recs + ((size_t)f * MAXQ + i) * MAXT;
+            CandRec* out = ws.cand_recs + ((size_t)f * ws.maxq + i) * MAXT;
             const int r = s_roi[qi];
             if (r < 0) {  // no quad in the crop: no candidate for this square (opencvar.cpp:704)
                 if (lane < T) out[lane].valid = 0;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             float pat[8], pts[8];
             for (int k = 0; k < 8; k++) {
                 pat[k] = (float)q.pt[k];
-                pts[k] = ws.squares[((size_t)f * MAXQ + i) * 8 + k];
+                pts[k] = ws.squares[((size_t)f * ws.maxq + i) * 8 + k];
             }
             const uint8_t* crop = ws.gray + (size_t)roi.frame * ws.W * ws.H + (size_t)roi.y0 * ws.W + roi.x0;
             for (int j = 0; j < T; j++) {   // in order: the orient 2/4 corner rotation leaks into the next template (D4)
@@ -105,12 +105,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
 }
 
-constexpr int MAXC = 2048;  // candidates per frame the tail keeps in LDS
+// (the tail keeps a frame's candidates in LDS: Workspace::maxc of them, 9 bytes each, sized at launch)
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8), amdgpu_num_vgpr(128))) void finalise_kernel(Workspace ws) {
-    __shared__ int s_mid[MAXC];
-    __shared__ int s_tid[MAXC];
-    __shared__ unsigned char s_score[MAXC];
+    extern __shared__ int tail_lds[];
+    const int MAXC = ws.maxc;
+    int* s_mid = tail_lds;
+    int* s_tid = tail_lds + MAXC;
+    unsigned char* s_score = reinterpret_cast<unsigned char*>(tail_lds + 2 * MAXC);
     __shared__ int s_src[MAXM];  // >= 0: candidate index, < 0: -(1 + index into prev)
     __shared__ int s_nout;
     const int f = blockIdx.x;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
     int n = 0;
     {
         int nsq = ws.n_squares[f];
-        nsq = nsq < MAXQ ? nsq : MAXQ;
+        nsq = nsq < ws.maxq ? nsq : ws.maxq;
         const int slots = nsq * T;
         bool overflow = false;
         for (int base = 0; base < slots; base += 64) {
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
             int orient = 0;
             bool valid = false;
             if (s < slots) {
-                const CandRec* c = ws.cand_recs + ((size_t)f * MAXQ + i) * MAXT + j;
+                const CandRec* c = ws.cand_recs + ((size_t)f * ws.maxq + i) * MAXT + j;
                 valid = c->valid != 0;
                 orient = c->orient;
             }
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
             m = ws.prev[(size_t)f * MAXM + (-src - 1)];  // square already updated by the tracking step
         } else {
             const int i = s_mid[src], j = s_tid[src];
-            const CandRec* c = ws.cand_recs + ((size_t)f * MAXQ + i) * MAXT + j;
+            const CandRec* c = ws.cand_recs + ((size_t)f * ws.maxq + i) * MAXT + j;
             const TemplateRec t = ws.templates[j];
             m.templateId = j;
             m.markerId = i;
@@ -220,7 +222,7 @@ void launch_decode(const Workspace& ws, hipStream_t stream) {
         hipLaunchKernelGGL(decode_kernel, dim3(ws.n_frames), dim3(256), (size_t)DECODE_CHUNK * ws.n_templates * 9 * sizeof(double), stream, ws);
 }
 void launch_finalise(const Workspace& ws, hipStream_t stream) {
-    if (ws.n_frames > 0) hipLaunchKernelGGL(finalise_kernel, dim3(ws.n_frames), dim3(64), 0, stream, ws);
+    if (ws.n_frames > 0) hipLaunchKernelGGL(finalise_kernel, dim3(ws.n_frames), dim3(64), (size_t)ws.maxc * 9 + 16, stream, ws);
 }
 
 }  // namespace ocvar

@@ -87,11 +87,11 @@ __device__ __forceinline__ void emit_quad(const Workspace& ws, const StartCand c
         atomicMin(ws.best_crop + c.roi, ((unsigned long long)(unsigned)c.pos << 32) | (unsigned)slot);
     } else {
         const int slot = atomicAdd(ws.n_quads_frame + c.roi, 1);
-        if (slot >= MAXQ) {
+        if (slot >= ws.maxq) {
             atomicOr(ws.counters + CNT_ERR, ERR_QUAD_OVERFLOW);
             return;
         }
-        ws.quads_frame[(size_t)c.roi * MAXQ + slot] = q;
+        ws.quads_frame[(size_t)c.roi * ws.maxq + slot] = q;
     }
 }
 
@@ -946,14 +946,15 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
 }
 
 __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
-    __shared__ int s_start[MAXQ];
-    __shared__ float s_sq[MAXQ][8];
+    extern __shared__ int order_lds[];              // [maxq] discovery positions, then [maxq][8] ordered corners
+    int* s_start = order_lds;
+    float (*s_sq)[8] = reinterpret_cast<float (*)[8]>(order_lds + ws.maxq);
     __shared__ int s_n;
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
     int n = ws.n_quads_frame[f];
-    if (n > MAXQ) n = MAXQ;
-    const QuadRec* q = ws.quads_frame + (size_t)f * MAXQ;
+    if (n > ws.maxq) n = ws.maxq;
+    const QuadRec* q = ws.quads_frame + (size_t)f * ws.maxq;
     for (int i = tid; i < n; i += blockDim.x) s_start[i] = q[i].start;
     __syncthreads();
     // sequence order of cvarFindSquares: contours come out last-discovered first (opencvar.cpp:187-214)
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
     __syncthreads();
     n = s_n;
     for (int i = tid; i < n; i += blockDim.x) {
-        float* out = ws.squares + ((size_t)f * MAXQ + i) * 8;
+        float* out = ws.squares + ((size_t)f * ws.maxq + i) * 8;
         int quad[8];
         for (int k = 0; k < 8; k++) {
             out[k] = s_sq[i][k];
@@ -1012,7 +1013,7 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
                 }
             }
         }
-        ws.crop_of[(size_t)f * MAXQ + i] = roi_index;
+        ws.crop_of[(size_t)f * ws.maxq + i] = roi_index;
     }
 }
 
@@ -1035,7 +1036,7 @@ void launch_follow_long_crops(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_long_kernel<true>, dim3(ws.long_blocks), dim3(256), 0, stream, ws);
 }
 void launch_order_and_crops(const Workspace& ws, hipStream_t stream) {
-    if (ws.n_frames > 0) hipLaunchKernelGGL(order_and_crops_kernel, dim3(ws.n_frames), dim3(256), 0, stream, ws);
+    if (ws.n_frames > 0) hipLaunchKernelGGL(order_and_crops_kernel, dim3(ws.n_frames), dim3(256), (size_t)ws.maxq * 9 * sizeof(int), stream, ws);
 }
 
 }  // namespace ocvar

@@ -8,7 +8,7 @@
 
 namespace ocvar {
 
-constexpr int MAXQ = OCVAR_MAX_QUADS;      // frame-pass quads kept per frame
+constexpr int MAXQ_DEFAULT = OCVAR_MAX_QUADS;   // frame-pass quads kept per frame unless the context was created for more (Workspace::maxq)
 constexpr int MAXM = OCVAR_MAX_MARKERS;    // markers kept per frame (tracked + new)
 constexpr int MAXT = OCVAR_MAX_TEMPLATES;
 constexpr int MARCH_HALO_L = 2, MARCH_HALO_R = 2;   // halo lanes (4 pixels each) left / right of a strip's output lanes
@@ -51,6 +51,8 @@ enum { CNT_FRAME_CANDS = 0, CNT_CROP_ROIS = 1, CNT_CROP_TILES = 2, CNT_CROP_CAND
 struct Workspace {
     // limits
     int max_w, max_h, max_batch;
+    int maxq;               // frame-pass quads kept per frame (ocvar_hip_create: OCVAR_MAX_QUADS; ocvar_hip_create_ex: caller's choice)
+    int maxc;               // pre-dedupe candidates per frame the tail can replay = maxq * n_templates, bounded by its LDS
     int cap_frame_cands, cap_crop_cands, cap_crop_rois, cap_crop_tiles, cap_crop_quads;
     long long cap_pool_ints, cap_crop_pixels;
     // per batch geometry
@@ -74,17 +76,17 @@ struct Workspace {
     int* pool;              // points + DP stacks
     int* slab;              // [max_mid_blocks*256][SLAB_STRIDE] private point space of the tier-2 lanes
     int* slab3;             // [max_long_blocks*4][SLAB3_STRIDE] point space of the tier-3 waves
-    QuadRec* quads_frame;   // [B][MAXQ] unordered
+    QuadRec* quads_frame;   // [B][maxq] unordered
     int* n_quads_frame;     // [B]
-    float* squares;         // [B][MAXQ][8] ordered, after tracking
+    float* squares;         // [B][maxq][8] ordered, after tracking
     int* n_squares;         // [B]
-    int* crop_of;           // [B][MAXQ] crop ROI index of square i, or -1
+    int* crop_of;           // [B][maxq] crop ROI index of square i, or -1
     Roi* rois_crop;
     TileDesc* tiles_crop;
     unsigned long long* crop_pixels;   // = counters + CNT_CROP_PIXELS: running sum of crop plane sizes (pool cursor)
     QuadRec* quads_crop;    // pool
     unsigned long long* best_crop;     // [cap_crop_rois] (start<<32 | quad slot), ~0 = none
-    CandRec* cand_recs;     // [B][MAXQ][MAXT]
+    CandRec* cand_recs;     // [B][maxq][MAXT]
     MarkerRec* prev;        // [B][MAXM]
     int* n_prev;            // [B]
     int* reserve;           // [B][MAXM] tracked marker indices

@@ -69,19 +69,25 @@ const CvPoint* seq_point(const CvSeq* seq, int i) {
 std::mutex g_mu;
 OcvarHip* g_ctx = nullptr;
 int g_w = 0, g_h = 0;
+int g_maxq = OCVAR_MAX_QUADS;   // squares per frame the current context has room for (grows when a frame needs more)
 std::deque<std::unique_ptr<OwnedSeq>> g_seqs;  // keeps returned sequences alive (the reference uses CvMemStorage)
 std::vector<CvarTemplate> g_templates;        // what the context currently holds: unchanged arguments are not uploaded again
 CvarCamera g_camera;
 bool g_have_camera = false;
 
-OcvarHip* context_for(int w, int h) {
-    if (g_ctx && w <= g_w && h <= g_h) return g_ctx;
+OcvarHip* context_for(int w, int h, int maxq = 0) {
+    if (maxq <= 0) maxq = g_maxq;
+    if (g_ctx && w <= g_w && h <= g_h && maxq <= g_maxq) return g_ctx;
+    if (g_ctx) {   // keep what the old context had room for
+        w = w > g_w ? w : g_w;
+        h = h > g_h ? h : g_h;
+    }
     if (g_ctx) ocvar_hip_destroy(g_ctx);
     g_ctx = nullptr;
     g_templates.clear();
     g_have_camera = false;
     const int dev = std::getenv("OCVAR_DEVICE") ? std::atoi(std::getenv("OCVAR_DEVICE")) : 0;
-    int rc = ocvar_hip_create(&g_ctx, dev, w < 64 ? 64 : w, h < 64 ? 64 : h, 1);
+    int rc = ocvar_hip_create_ex(&g_ctx, dev, w < 64 ? 64 : w, h < 64 ? 64 : h, 1, maxq);
     if (rc != OCVAR_OK) {
         std::fprintf(stderr, "opencvar: no MI355X context (%d): %s\n", rc, g_ctx ? ocvar_hip_last_error(g_ctx) : "no gfx950 device");
         if (g_ctx) ocvar_hip_destroy(g_ctx);
@@ -90,6 +96,7 @@ OcvarHip* context_for(int w, int h) {
     }
     g_w = w < 64 ? 64 : w;
     g_h = h < 64 ? 64 : h;
+    g_maxq = maxq;
     return g_ctx;
 }
 
@@ -421,14 +428,22 @@ CvSeq* cvarFindSquares(IplImage* img, CvMemStorage* /*storage*/) {
                 told = true;
                 std::fprintf(stderr, "opencvar: cvarFindSquares: colour image greyed before the pyramid filter (the reference filters per channel)\n");
             }
-            // (more than OCVAR_MAX_QUADS squares in one image: the call fails with OCVAR_E_CAPACITY, reported below)
-            std::vector<int> quads((size_t)OCVAR_MAX_QUADS * 8);
-            int n = 0;
-            const int rc = ocvar_hip_find_squares(ctx, gray.data(), img->width, img->height, img->width, quads.data(), OCVAR_MAX_QUADS, &n);
+            // the reference's square list is unbounded (opencvar.cpp:187-214): an image with more squares than the context has
+            // room for is run again on a larger one (256 -> 1024 -> OCVAR_MAX_QUADS_EX); beyond that the failure is reported
+            std::vector<int> quads;
+            int n = 0, rc = OCVAR_OK;
+            for (;;) {
+                quads.assign((size_t)g_maxq * 8, 0);
+                rc = ocvar_hip_find_squares(ctx, gray.data(), img->width, img->height, img->width, quads.data(), g_maxq, &n);
+                if (rc != OCVAR_E_CAPACITY || !(ocvar_hip_capacity_flags(ctx) & 4) || g_maxq >= OCVAR_MAX_QUADS_EX) break;
+                ctx = context_for(img->width, img->height, g_maxq * 4 < OCVAR_MAX_QUADS_EX ? g_maxq * 4 : OCVAR_MAX_QUADS_EX);
+                if (!ctx) break;
+            }
+            if (!ctx) rc = OCVAR_E_HIP;
             if (rc == OCVAR_OK) {
                 for (int i = 0; i < 4 * n; i++) seq->pts.push_back(CvPoint{quads[2 * i], quads[2 * i + 1]});
             } else {
-                std::fprintf(stderr, "opencvar: cvarFindSquares failed: %s\n", ocvar_hip_last_error(ctx));
+                std::fprintf(stderr, "opencvar: cvarFindSquares failed: %s\n", ctx ? ocvar_hip_last_error(ctx) : "no context");
             }
         }
     }
@@ -548,27 +563,6 @@ int cvarArMultRegistration(IplImage* image, vector<CvarMarker>* markers, vector<
         markers->clear();
         return 0;
     }
-    OcvarHip* ctx = context_for(image->width, image->height);
-    if (!ctx) {
-        markers->clear();
-        return 0;
-    }
-    // templates and camera are uploaded only when they differ from what the context holds (a caller passes the same ones
-    // frame after frame, ARTest.cpp:57)
-    const bool same_t = g_templates.size() == templates.size() &&
-                        std::memcmp(g_templates.data(), templates.data(), templates.size() * sizeof(CvarTemplate)) == 0;
-    const bool same_c = g_have_camera && std::memcmp(&g_camera, camera, sizeof(CvarCamera)) == 0;
-    if ((!same_t && ocvar_hip_set_templates(ctx, reinterpret_cast<const OcvarTemplate*>(templates.data()), (int)templates.size()) != OCVAR_OK) ||
-        (!same_c && ocvar_hip_set_camera(ctx, reinterpret_cast<const OcvarCamera*>(camera)) != OCVAR_OK)) {
-        std::fprintf(stderr, "opencvar: %s\n", ocvar_hip_last_error(ctx));
-        g_templates.clear();
-        g_have_camera = false;
-        markers->clear();
-        return 0;
-    }
-    g_templates = templates;
-    g_camera = *camera;
-    g_have_camera = true;
     if (markers->size() > OCVAR_MAX_MARKERS) {
         std::fprintf(stderr, "opencvar: cvarArMultRegistration: %zu markers carried in, this build tracks at most %d per frame\n",
                      markers->size(), OCVAR_MAX_MARKERS);
@@ -579,10 +573,38 @@ int cvarArMultRegistration(IplImage* image, vector<CvarMarker>* markers, vector<
     int n_prev = (int)markers->size();
     if (n_prev) std::memcpy(prev.data(), markers->data(), n_prev * sizeof(OcvarMarker));
     std::vector<OcvarMarker> out(OCVAR_MAX_MARKERS);
-    int count = 0;
-    const int rc = ocvar_hip_detect_host(ctx, (uint8_t*)image->imageData, image->width, image->height, image->widthStep,
-                                         (size_t)image->widthStep * image->height, 1, 1, n_prev ? prev.data() : nullptr,
-                                         n_prev ? &n_prev : nullptr, out.data(), &count, OCVAR_MAX_MARKERS);
+    int count = 0, rc = OCVAR_OK;
+    OcvarHip* ctx = context_for(image->width, image->height);
+    for (;;) {
+        if (!ctx) {
+            markers->clear();
+            return 0;
+        }
+        // templates and camera are uploaded only when they differ from what the context holds (a caller passes the same
+        // ones frame after frame, ARTest.cpp:57)
+        const bool same_t = g_templates.size() == templates.size() &&
+                            std::memcmp(g_templates.data(), templates.data(), templates.size() * sizeof(CvarTemplate)) == 0;
+        const bool same_c = g_have_camera && std::memcmp(&g_camera, camera, sizeof(CvarCamera)) == 0;
+        if ((!same_t && ocvar_hip_set_templates(ctx, reinterpret_cast<const OcvarTemplate*>(templates.data()), (int)templates.size()) != OCVAR_OK) ||
+            (!same_c && ocvar_hip_set_camera(ctx, reinterpret_cast<const OcvarCamera*>(camera)) != OCVAR_OK)) {
+            std::fprintf(stderr, "opencvar: %s\n", ocvar_hip_last_error(ctx));
+            g_templates.clear();
+            g_have_camera = false;
+            markers->clear();
+            return 0;
+        }
+        g_templates = templates;
+        g_camera = *camera;
+        g_have_camera = true;
+        rc = ocvar_hip_detect_host(ctx, (uint8_t*)image->imageData, image->width, image->height, image->widthStep,
+                                   (size_t)image->widthStep * image->height, 1, 1, n_prev ? prev.data() : nullptr,
+                                   n_prev ? &n_prev : nullptr, out.data(), &count, OCVAR_MAX_MARKERS);
+        // The reference's square list is unbounded (opencvar.cpp:187-214).  A frame with more squares (or candidates) than
+        // the context has room for fails before the caller's image is touched; it is run again on a larger context
+        // (256 -> 1024 -> OCVAR_MAX_QUADS_EX squares), which is then kept.
+        if (rc != OCVAR_E_CAPACITY || !(ocvar_hip_capacity_flags(ctx) & 4) || g_maxq >= OCVAR_MAX_QUADS_EX) break;
+        ctx = context_for(image->width, image->height, g_maxq * 4 < OCVAR_MAX_QUADS_EX ? g_maxq * 4 : OCVAR_MAX_QUADS_EX);
+    }
     markers->clear();
     if (rc != OCVAR_OK) {
         std::fprintf(stderr, "opencvar: detection failed (%d): %s\n", rc, ocvar_hip_last_error(ctx));

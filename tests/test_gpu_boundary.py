@@ -179,3 +179,54 @@ def test_rccl_gather_of_result_blocks_world1():
             assert m.tobytes() == markers[f, :c].tobytes()
     finally:
         dist.destroy_process_group()
+
+
+def _grid_of_squares(w, h, pitch=44, side=30):
+    g = np.full((h, w), 200, np.uint8)
+    for y in range(20, h - side - 20, pitch):
+        for x in range(20, w - side - 20, pitch):
+            g[y:y + side, x:x + side] = 40
+    return g
+
+
+def test_more_squares_than_the_default_list_holds(host):
+    """The reference's square list is unbounded (opencvar.cpp:187-214).  An image with more than OCVAR_MAX_QUADS (256)
+    squares is run again on a context with a longer list by the host mirror: same sequence as the oracle, in order."""
+    g = _grid_of_squares(1280, 960)
+    ref = H.oracle_find_squares(g)
+    assert len(ref) > 256
+    img_arr = np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
+    img = ipl(img_arr)
+    seq = host.cvarFindSquares(C.byref(img), None)
+    assert seq.contents.total == 4 * len(ref)
+    assert np.array_equal(seq_points(seq), ref)
+
+
+def test_registration_of_a_frame_with_hundreds_of_squares():
+    """cvarArMultRegistration through libopencv-ar.so on a frame whose frame pass yields > 256 squares (and > 256 crops):
+    the C ABI reports OCVAR_E_CAPACITY on a default context; one created with ocvar_hip_create_ex equals the oracle."""
+    import torch
+    import opencv_ar_amd as oa
+    g = _grid_of_squares(1280, 960)
+    frame = np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
+    tpls, cam = H.oracle_templates(["2x2-01"]), H.oracle_camera(1280, 960)
+    ref_m, ref_c, _ = H.oracle_registration(frame, tpls, cam)
+    small = oa.Detector(1280, 960, max_batch=1)
+    small.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls])
+    small.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+    with pytest.raises(oa.OcvarError):
+        small.detect_host(frame[None].copy())
+    assert oa.hip_lib().ocvar_hip_capacity_flags(small._ctx) & 4
+    lib = oa.hip_lib()
+    lib.ocvar_hip_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    big = oa.Detector.__new__(oa.Detector)
+    big._lib, big._ctx, big.max_batch, big.n_templates = lib, C.c_void_p(), 1, 0
+    assert lib.ocvar_hip_create_ex(C.byref(big._ctx), 0, 1280, 960, 1, 1024) == 0
+    big.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls])
+    big.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+    markers, counts = big.detect_host(frame[None].copy())
+    assert counts[0] == len(ref_m)
+    for k, r in enumerate(ref_m):
+        assert markers[0, k]["templateId"] == r.templateId and markers[0, k]["markerId"] == r.markerId
+        gm = np.array(r.glMatrix)
+        assert np.abs(markers[0, k]["glMatrix"] - gm).max() <= 1e-4 * max(1.0, np.abs(gm).max())
