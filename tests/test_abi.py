@@ -42,3 +42,24 @@ def test_no_cpu_fallback_without_device(pkg):
 def test_synth_library_symbols():
     lib = H.synth_lib()
     assert hasattr(lib, "ocvar_synth_frame") and hasattr(lib, "ocvar_synth_config")
+
+
+def test_multi_gpu_library_exports_declared_symbols(pkg):
+    """include/ocvar_multi.h (one process, N GPUs, RCCL gather): every declared entry point is exported by
+    lib/libocvar_multi.so, which resolves against librccl and the single-GPU library."""
+    pkg.hip_lib()
+    lib = C.CDLL(os.path.join(pkg.LIB_DIR, "libocvar_multi.so"))
+    header = open(os.path.join(H.ROOT, "include", "ocvar_multi.h")).read()
+    declared = sorted(set(re.findall(r"\b(ocvar_multi_\w+)\s*\(", header)))
+    assert declared == ["ocvar_multi_create", "ocvar_multi_destroy", "ocvar_multi_detect_device", "ocvar_multi_detect_host",
+                        "ocvar_multi_devices", "ocvar_multi_last_error", "ocvar_multi_set_camera", "ocvar_multi_set_templates"]
+    for name in declared:
+        assert hasattr(lib, name), name
+    import torch
+    if not torch.cuda.is_available():   # no device: creation fails loudly, there is no CPU path
+        m = C.c_void_p()
+        lib.ocvar_multi_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        assert lib.ocvar_multi_create(C.byref(m), None, 1, 640, 480, 1) != 0
+        if m:
+            lib.ocvar_multi_destroy.argtypes = [C.c_void_p]
+            lib.ocvar_multi_destroy(m)
