@@ -66,7 +66,10 @@ extern "C" int ocvar_hip_create(OcvarHip** out, int device, int max_width, int m
 }
 
 extern "C" int ocvar_hip_create_ex(OcvarHip** out, int device, int max_width, int max_height, int max_batch, int max_quads) {
-    if (!out || max_width < 16 || max_height < 16 || max_batch < 1 || max_quads < 1 || max_quads > OCVAR_MAX_QUADS_EX) return OCVAR_E_ARG;
+    // (corner points travel packed as x | y << 16 through the follower tiers: coordinates stay below 2^15)
+    if (!out || max_width < 16 || max_height < 16 || max_width > 32767 || max_height > 32767 || max_batch < 1 || max_quads < 1 ||
+        max_quads > OCVAR_MAX_QUADS_EX)
+        return OCVAR_E_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return OCVAR_E_NO_DEVICE;
