@@ -257,9 +257,10 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     unsigned ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0;  // horizontal pyrDown sums of the last 5 rows (a | b<<16)
     unsigned prevP = 0;                      // previous pyramid row for the bottom border
     unsigned rAe = 0, rAo = 0, rBe = 0, rBo = 0;   // up-sampled pyramid rows q-2, q-1: even columns (r0|r2<<16), odd (r1|r3<<16)
-    unsigned we[7], wo[7];                   // the last 7 (virtual) pyrUp rows, newest last: even columns (u0|u2<<16), odd (u1|u3<<16)
-#pragma unroll
-    for (int k = 0; k < 7; k++) we[k] = wo[k] = 0;
+    // The last 8 (virtual) pyrUp rows, one pair of registers per pixel with a row per byte: wa[p] = rows vu-3 .. vu (newest in
+    // the high byte), wb[p] = rows vu-7 .. vu-4.  A new row is two byte permutes per pixel (no window of registers to shift),
+    // and the vertical 7-tap Gaussian of a pixel is two v_dot4_u32_u8.
+    unsigned wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
     unsigned m_prev = 0, u_prev = 0, x_prev = 0;   // mask of row y-1 still without its row below; what row y-1 gives to the row below it; its start nibbles
 
     Raw nxt = fetch(v_first);
@@ -334,22 +335,24 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                 // rows above 0 / below sh-1 replicate row 0 / sh-1; one more virtual row flushes the last mask row
                 const int vlo = (u == 0) ? -3 : u, vhi = (u == sh - 1) ? sh + 3 : u;
                 for (int vu = vlo; vu <= vhi; vu++) {
+                    {
+                        const unsigned U4 = as_u32(Ue) | (as_u32(Uo) << 8);   // u0 u1 u2 u3 as bytes (each <= 255)
 #pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        we[k] = we[k + 1];
-                        wo[k] = wo[k + 1];
+                        for (int p = 0; p < 4; p++) {
+                            wb[p] = __builtin_amdgcn_perm(wa[p], wb[p], 0x04030201u);             // drop the oldest row, take wa's oldest
+                            wa[p] = __builtin_amdgcn_perm(U4, wa[p], 0x04030201u + ((unsigned)p << 24));   // ... and pixel p of the new row
+                        }
                     }
-                    we[6] = as_u32(Ue);
-                    wo[6] = as_u32(Uo);
                     const int y = vu - 3;   // the window now holds pyrUp rows y-3 .. y+3
                     if (y < Y0 - 1 || y > Y1 || y < 0) continue;
                     unsigned nib = 0;
                     if (y >= 1 && y <= sh - 2) {
-                        // 7x7 Gaussian, vertical pass first: [8 28 56 72 56 28 8] on packed 16-bit pairs (<= 256*255 fits)
-                        const us2 Ve = (as_us2(we[0]) + as_us2(we[6])) * (unsigned short)8 + (as_us2(we[1]) + as_us2(we[5])) * (unsigned short)28 +
-                                       (as_us2(we[2]) + as_us2(we[4])) * (unsigned short)56 + as_us2(we[3]) * (unsigned short)72;
-                        const us2 Vo = (as_us2(wo[0]) + as_us2(wo[6])) * (unsigned short)8 + (as_us2(wo[1]) + as_us2(wo[5])) * (unsigned short)28 +
-                                       (as_us2(wo[2]) + as_us2(wo[4])) * (unsigned short)56 + as_us2(wo[3]) * (unsigned short)72;
+                        // 7x7 Gaussian, vertical pass first: [8 28 56 72 56 28 8] over rows y-3 .. y+3 = bytes 1..3 of wb, 0..3 of wa
+                        // (<= 256*255: the sums fit 16 bits and are packed in pairs for the horizontal pass)
+                        unsigned V[4];
+#pragma unroll
+                        for (int p = 0; p < 4; p++) V[p] = dot4(wa[p], 72u | (56u << 8) | (28u << 16) | (8u << 24), dot4(wb[p], (8u << 8) | (28u << 16) | (56u << 24), 0u));
+                        const us2 Ve = as_us2(V[0] | (V[2] << 16)), Vo = as_us2(V[1] | (V[3] << 16));
                         // horizontal pass: 16-bit column sums of this lane (V0..V3 = Ve.x Vo.x Ve.y Vo.y), the lane to the
                         // left (l) and to the right (r), two taps per v_dot2_u32_u16.  The accumulator starts at the
                         // rounding constant minus 8<<16:  src - mean > -8  <=>  sum + 32768 - (8<<16) < src<<16
@@ -360,13 +363,13 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                         const unsigned S1 = dot2(Vel, K2(0, 8), dot2(Vol, K2(0, 28), dot2(Ve, K2(56, 56), dot2(Vo, K2(72, 28), dot2(Ver, K2(8, 0), C0)))));
                         const unsigned S2 = dot2(Vol, K2(0, 8), dot2(Ve, K2(28, 72), dot2(Vo, K2(56, 56), dot2(Ver, K2(28, 0), dot2(Vor, K2(8, 0), C0)))));
                         const unsigned S3 = dot2(Ve, K2(8, 56), dot2(Vo, K2(28, 72), dot2(Ver, K2(56, 8), dot2(Vor, K2(28, 0), C0))));
-                        const unsigned ce = we[3], co = wo[3];   // pyrUp row y itself: the threshold's source
-                        // nib = 2 * nib + (S < src << 16), pixel 3 first: one compare and one add-with-carry per pixel
-#define OCVAR_PUSH_BIT(S, RHS) asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nib) : "v"(S), "v"(RHS) : "vcc")
-                        OCVAR_PUSH_BIT(S3, co & 0xffff0000u);
-                        OCVAR_PUSH_BIT(S2, ce & 0xffff0000u);
-                        OCVAR_PUSH_BIT(S1, co << 16);
-                        OCVAR_PUSH_BIT(S0, ce << 16);
+                        // pyrUp row y itself -- byte 0 of wa -- is the threshold's source; nib = 2 * nib + (S < src << 16), pixel 3
+                        // first: one compare and one add-with-carry per pixel
+#define OCVAR_PUSH_BIT(S, P) asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nib) : "v"(S), "v"(__builtin_amdgcn_perm(wa[P], wa[P], 0x0c000c0cu)) : "vcc")
+                        OCVAR_PUSH_BIT(S3, 3);
+                        OCVAR_PUSH_BIT(S2, 2);
+                        OCVAR_PUSH_BIT(S1, 1);
+                        OCVAR_PUSH_BIT(S0, 0);
 #undef OCVAR_PUSH_BIT
                         nib &= colmask;
                     }
