@@ -35,6 +35,8 @@ struct OcvarHip {
     std::vector<hipEvent_t> h2d_done;
     hipEvent_t computed = nullptr;
     MarkerRec* h_markers = nullptr;  // pinned
+    MarkerRec* h_prev = nullptr;     // pinned: the caller's previous markers on their way to the device
+    int* h_prev_counts = nullptr;    // pinned
     int* h_counts = nullptr;         // pinned
     int* h_counters = nullptr;       // pinned
     bool pending = false;
@@ -155,6 +157,8 @@ extern "C" int ocvar_hip_create_ex(OcvarHip** out, int device, int max_width, in
     HIP_TRY(c, hipMemset(w.counters, 0, CNT_COUNT * sizeof(int)));
     HIP_TRY(c, hipHostMalloc((void**)&c->h_markers, B * MAXM * sizeof(MarkerRec)));
     HIP_TRY(c, hipHostMalloc((void**)&c->h_counts, B * sizeof(int)));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_prev, B * MAXM * sizeof(MarkerRec)));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_prev_counts, B * sizeof(int)));
     HIP_TRY(c, hipHostMalloc((void**)&c->h_counters, CNT_COUNT * sizeof(int)));
     return OCVAR_OK;
 }
@@ -168,6 +172,8 @@ extern "C" void ocvar_hip_destroy(OcvarHip* c) {
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_markers) (void)hipHostFree(c->h_markers);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->h_prev) (void)hipHostFree(c->h_prev);
+    if (c->h_prev_counts) (void)hipHostFree(c->h_prev_counts);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -224,6 +230,10 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     if (!d_bgr || width < 16 || height < 16 || width > w.max_w || height > w.max_h || n_frames < 1 || n_frames > w.max_batch ||
         (size_t)width * height > (size_t)w.max_w * w.max_h || row_stride < 3 * width)
         return OCVAR_E_ARG;
+    if (c->pending) {
+        c->err = "the previous batch of this context has not been collected";
+        return OCVAR_E_ARG;
+    }
     if (stages > 2 && (!c->have_templates || !c->have_camera)) {
         c->err = "templates and camera must be set before detection";
         return OCVAR_E_ARG;
@@ -261,8 +271,12 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     HIP_TRY(c, hipMemsetAsync(w.counters, 0, CNT_COUNT * sizeof(int), s));
     HIP_TRY(c, hipMemsetAsync(w.n_quads_frame, 0, n_frames * sizeof(int), s));
     if (prev && prev_counts) {
-        HIP_TRY(c, hipMemcpyAsync(w.prev, prev, (size_t)n_frames * MAXM * sizeof(MarkerRec), hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(w.n_prev, prev_counts, n_frames * sizeof(int), hipMemcpyHostToDevice, s));
+        // through the context's page-locked buffers: the device never touches the caller's (pageable, possibly tiny) arrays.
+        // (A batch is collected before the next one is enqueued on a context, so the buffers are free again by then.)
+        std::memcpy(c->h_prev, prev, (size_t)n_frames * MAXM * sizeof(MarkerRec));
+        std::memcpy(c->h_prev_counts, prev_counts, n_frames * sizeof(int));
+        HIP_TRY(c, hipMemcpyAsync(w.prev, c->h_prev, (size_t)n_frames * MAXM * sizeof(MarkerRec), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(w.n_prev, c->h_prev_counts, n_frames * sizeof(int), hipMemcpyHostToDevice, s));
     } else {
         HIP_TRY(c, hipMemsetAsync(w.n_prev, 0, n_frames * sizeof(int), s));
     }
@@ -427,8 +441,10 @@ extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int
     int rc = reserve_staging(c, bytes);
     if (rc) return rc;
 
+    // Page-locking the caller's buffer in place pays off (and is only done) for batches of several megabytes; small ones --
+    // a handful of small frames in a heap block that shares its pages with other data -- go through the bounce buffer.
     bool registered_here = false, pinned = false;
-    if (n_frames > 1) {
+    if (n_frames > 1 && bytes >= ((size_t)8 << 20)) {
         const hipError_t e = hipHostRegister(h_bgr, bytes, hipHostRegisterDefault);
         if (e == hipSuccess) registered_here = pinned = true;
         else if (e == hipErrorHostMemoryAlreadyRegistered) pinned = true;
