@@ -16,6 +16,7 @@
 //   Gaussian [8 28 56 72 56 28 8]^2, (v+32768)>>16, BORDER_REPLICATE    threshold  src - mean > -8
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace ocvar {
 
@@ -208,9 +209,9 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
 
     // raw source words of virtual row v (3 dwords BGR / 1 dword grey for fast lanes, 4 pixels for edge lanes)
     struct Raw { unsigned d0, d1, d2; };
-    auto fetch = [&](int v) -> Raw {
+    auto fetch = [&](int v, bool inside /* 0 <= v < sh is known */) -> Raw {
         Raw r = {0u, 0u, 0u};
-        const uint8_t* row = src + wave_uniform64((long long)reflect101(v, sh) * src_stride);
+        const uint8_t* row = src + wave_uniform64((long long)(inside ? v : reflect101(v, sh)) * src_stride);
         if (plan) {
             __builtin_memcpy(&r, row + goff, BGR ? 12 : 4);   // unaligned global_load_dword / dwordx3
             return r;
@@ -263,13 +264,17 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     unsigned wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
     unsigned m_prev = 0, u_prev = 0, x_prev = 0;   // mask of row y-1 still without its row below; what row y-1 gives to the row below it; its start nibbles
 
-    Raw nxt = fetch(v_first);
-    for (int v = v_first; v <= v_last; v++) {
+    // One source row.  S ("steady"): v lies where every range test below has a known outcome -- the rows it completes are
+    // inside the work unit and away from the image's first and last rows -- so the tests (a scalar compare and branch
+    // each, dozens per row) are compiled out; the rows at the top and bottom of a unit take the generic instance.
+    Raw nxt = fetch(v_first, false);
+    auto row = [&](const int v, auto steady_tag) {
+        constexpr bool S = decltype(steady_tag)::value;
         const Raw cur = nxt;
-        if (v < v_last) nxt = fetch(v + 1);  // issue the next row's loads before this row's arithmetic
+        if (S || v < v_last) nxt = fetch(v + 1, S);  // issue the next row's loads before this row's arithmetic
         unsigned g = to_grey(cur);
         if (plan && permuted) g = __builtin_amdgcn_perm(g, g, gsel);
-        if (BGR && o.gray && out_lane && v >= Y0 && v < Y1) {  // rows [Y0,Y1) are real rows, each loaded exactly once
+        if (BGR && o.gray && out_lane && (S || (v >= Y0 && v < Y1))) {  // rows [Y0,Y1) are real rows, each loaded exactly once
             uint8_t* q = o.gray + wave_uniform64((long long)v * o.gray_stride) + out_off;
             if (gray_dword) *reinterpret_cast<unsigned*>(q) = g;
             else
@@ -283,7 +288,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
             ph0 = ph1; ph1 = ph2; ph2 = ph3; ph3 = ph4;
             ph4 = a | (b << 16);
         }
-        if ((v & 1) || v < v_first + 4) continue;
+        if ((v & 1) || (!S && v < v_first + 4)) return;
         const int q = (v - 2) >> 1;  // pyramid row completed by source row 2q+2
         us2 P = (as_us2(ph0) + as_us2(ph4) + (as_us2(ph1) + as_us2(ph3)) * (unsigned short)4 + as_us2(ph2) * (unsigned short)6 +
                  (unsigned short)128) >> (unsigned short)8;
@@ -292,8 +297,8 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
             if (k0 + 1 == pw) P.y = P.x;
             if (k0 == pw) P.x = (unsigned short)(left >> 16);
         }
-        if (q == ph_) P = as_us2(prevP);       // pyrUp bottom border: row ph stands for row ph-1
-        else if (q < ph_) prevP = as_u32(P);
+        if (!S && q == ph_) P = as_us2(prevP);       // pyrUp bottom border: row ph stands for row ph-1
+        else if (S || q < ph_) prevP = as_u32(P);
         unsigned rCe, rCo;
         {   // horizontal up-sampling at the lane's 4 columns: even (r0,r2) and odd (r1,r3)
             const unsigned pk = as_u32(P);
@@ -302,10 +307,10 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
             rCe = as_u32(Lv + P * (unsigned short)6 + Rv);
             rCo = as_u32((P + Rv) * (unsigned short)4);
         }
-        if (q >= qa + 2) {
+        if (S || q >= qa + 2) {
             for (int par = 0; par < 2; par++) {
                 const int u = 2 * (q - 1) + par;
-                if (u < 0 || u >= sh) continue;
+                if (!S && (u < 0 || u >= sh)) continue;
                 us2 Ue, Uo;   // pyrUp row u at the lane's even columns (c0, c0+2) and odd columns (c0+1, c0+3)
                 if (par == 0) {
                     Ue = (as_us2(rAe) + as_us2(rBe) * (unsigned short)6 + as_us2(rCe) + (unsigned short)32) >> (unsigned short)6;
@@ -333,7 +338,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                     }
                 }
                 // rows above 0 / below sh-1 replicate row 0 / sh-1; one more virtual row flushes the last mask row
-                const int vlo = (u == 0) ? -3 : u, vhi = (u == sh - 1) ? sh + 3 : u;
+                const int vlo = (!S && u == 0) ? -3 : u, vhi = (!S && u == sh - 1) ? sh + 3 : u;
                 for (int vu = vlo; vu <= vhi; vu++) {
                     {
                         const unsigned U4 = as_u32(Ue) | (as_u32(Uo) << 8);   // u0 u1 u2 u3 as bytes (each <= 255)
@@ -344,9 +349,9 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                         }
                     }
                     const int y = vu - 3;   // the window now holds pyrUp rows y-3 .. y+3
-                    if (y < Y0 - 1 || y > Y1 || y < 0) continue;
+                    if (!S && (y < Y0 - 1 || y > Y1 || y < 0)) continue;
                     unsigned nib = 0;
-                    if (y >= 1 && y <= sh - 2) {
+                    if (S || (y >= 1 && y <= sh - 2)) {
                         // 7x7 Gaussian, vertical pass first: [8 28 56 72 56 28 8] over rows y-3 .. y+3 = bytes 1..3 of wb, 0..3 of wa
                         // (<= 256*255: the sums fit 16 bits and are packed in pairs for the horizontal pass)
                         unsigned V[4];
@@ -383,16 +388,16 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                     x_prev = T.w;
                     st = st & ~(st >> 4) & pxsel;              // bits 0..3: outer starts, bits 8..11: hole starts of row y
                     const int yr = y - 1;
-                    if (yr >= Y0 && yr < Y1) {
+                    if (S || (yr >= Y0 && yr < Y1)) {
                         rowbuf[(yr & 7) * 64 + lane] = nbr4;
-                        if ((yr & 7) == 7 || yr == Y1 - 1) flush_rows(yr);
+                        if ((yr & 7) == 7 || (!S && yr == Y1 - 1)) flush_rows(yr);
                     }
                     // Plausible border starts of row y (sparse): necessary local conditions for being the raster-first pixel of
                     // a region.  Outer: foreground pixel whose W, NW, N, NE are background -- and not (E foreground and the pixel
                     // above E's east neighbour foreground: that one belongs to the same 8-connected component and comes earlier).
                     // Hole: background pixel whose W and N are foreground -- and E or NE foreground (if both are background they
                     // belong to the same 4-connected background region and NE comes earlier).
-                    if (y < Y0 || y >= Y1 || __ballot(st != 0) == 0) continue;
+                    if ((!S && (y < Y0 || y >= Y1)) || __ballot(st != 0) == 0) continue;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const int type = ((st >> j) & 1u) ? 0 : ((st >> (8 + j)) & 1u) ? 1 : -1;
@@ -408,7 +413,15 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         }
         rAe = rBe; rAo = rBo;
         rBe = rCe; rBo = rCo;
-    }
+    };
+    // steady rows: v and v+1 are real rows of this unit ([Y0, Y1), v+1 <= sh-1), and the rows an even v completes -- pyrUp
+    // rows v-4, v-3, threshold rows v-7, v-6, mask rows v-8, v-7 -- are inside the unit, at least one row away from the
+    // image's top and bottom (no replicated pyrUp rows, no zeroed contour-frame rows) and not the unit's last mask row
+    const int vs0 = Y0 + 8 > 8 ? Y0 + 8 : 8, vs1 = Y1 - 1 < sh - 2 ? Y1 - 1 : sh - 2;
+    int v = v_first;
+    for (; v <= v_last && v < vs0; v++) row(v, std::false_type());
+    for (; v <= vs1; v++) row(v, std::true_type());
+    for (; v <= v_last; v++) row(v, std::false_type());
     flush();
 }
 
