@@ -268,8 +268,9 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     // inside the work unit and away from the image's first and last rows -- so the tests (a scalar compare and branch
     // each, dozens per row) are compiled out; the rows at the top and bottom of a unit take the generic instance.
     Raw nxt = fetch(v_first, false);
-    auto row = [&](const int v, auto steady_tag) {
+    auto row = [&](const int v, auto steady_tag, auto parity_tag) {
         constexpr bool S = decltype(steady_tag)::value;
+        constexpr int PAR = decltype(parity_tag)::value;   // 1: v is odd, 2: v is even, 0: not known at compile time
         const Raw cur = nxt;
         if (S || v < v_last) nxt = fetch(v + 1, S);  // issue the next row's loads before this row's arithmetic
         unsigned g = to_grey(cur);
@@ -288,7 +289,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
             ph0 = ph1; ph1 = ph2; ph2 = ph3; ph3 = ph4;
             ph4 = a | (b << 16);
         }
-        if ((v & 1) || (!S && v < v_first + 4)) return;
+        if (PAR == 1 || (PAR == 0 && ((v & 1) || (!S && v < v_first + 4)))) return;
         const int q = (v - 2) >> 1;  // pyramid row completed by source row 2q+2
         us2 P = (as_us2(ph0) + as_us2(ph4) + (as_us2(ph1) + as_us2(ph3)) * (unsigned short)4 + as_us2(ph2) * (unsigned short)6 +
                  (unsigned short)128) >> (unsigned short)8;
@@ -417,11 +418,21 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     // steady rows: v and v+1 are real rows of this unit ([Y0, Y1), v+1 <= sh-1), and the rows an even v completes -- pyrUp
     // rows v-4, v-3, threshold rows v-7, v-6, mask rows v-8, v-7 -- are inside the unit, at least one row away from the
     // image's top and bottom (no replicated pyrUp rows, no zeroed contour-frame rows) and not the unit's last mask row
-    const int vs0 = Y0 + 8 > 8 ? Y0 + 8 : 8, vs1 = Y1 - 1 < sh - 2 ? Y1 - 1 : sh - 2;
+    const int vs0 = (Y0 + 8 > 8 ? Y0 + 8 : 8) | 1, vs1 = Y1 - 1 < sh - 2 ? Y1 - 1 : sh - 2;   // (vs0 odd: steady rows run in pairs)
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
     int v = v_first;
-    for (; v <= v_last && v < vs0; v++) row(v, std::false_type());
-    for (; v <= vs1; v++) row(v, std::true_type());
-    for (; v <= v_last; v++) row(v, std::false_type());
+#pragma nounroll
+    for (int phase = 0; phase < 2; phase++) {   // generic rows, steady pairs, generic rows: one copy of each instance
+        const int end = phase == 0 ? (vs0 <= v_last + 1 ? vs0 : v_last + 1) : v_last + 1;
+        for (; v < end; v++) row(v, std::false_type(), P0());
+        if (phase == 0)
+            for (; v + 1 <= vs1; v += 2) {
+                row(v, std::true_type(), P1());
+                row(v + 1, std::true_type(), P2());
+            }
+    }
     flush();
 }
 
