@@ -109,7 +109,9 @@ struct MarchOut {
 };
 
 // One work unit: strip `strip` of an (sw x sh) ROI, output rows [Y0, Y1).
-template <bool BGR>
+// EDGE = false: the strip lies strictly inside the image (no lane holds a column < 0 or >= sw), so the border rules of the
+// filters and their lane masks are compiled out -- six of a 1080p frame's eight strips; a crop's strips always touch an edge.
+template <bool BGR, bool EDGE>
 __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int sh, int strip, int Y0, int Y1, const MarchOut& o,
                            unsigned* stage, unsigned* rowbuf /* LDS, 8 rows x 64 lanes */, const uint4* tab /* LDS, mask_table_entry */) {
     const int lane = threadIdx.x & 63;
@@ -117,14 +119,14 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     const int c0 = XS + 4 * lane;
     const int pw = sw >> 1, ph_ = sh >> 1;
     const int k0 = c0 >> 1;  // pyramid column of the lane's first pyramid sample (c0 is a multiple of 4)
-    const bool out_lane = lane >= HL && lane < 64 - HR && c0 < sw;
-    const bool needed = c0 + 3 >= -16 && c0 < sw + 16;  // beyond every halo: never consumed
-    const bool fast = c0 >= 0 && c0 + 3 < sw;
+    const bool out_lane = lane >= HL && lane < 64 - HR && (!EDGE || c0 < sw);
+    const bool needed = !EDGE || (c0 + 3 >= -16 && c0 < sw + 16);  // beyond every halo: never consumed
+    const bool fast = !EDGE || (c0 >= 0 && c0 + 3 < sw);
     const bool aligned = BGR ? ((src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) : true;
-    const bool left_edge = strip == 0;             // lanes 0..HL-1 hold virtual columns -4*HL..-1
+    const bool left_edge = EDGE && strip == 0;     // lanes 0..HL-1 hold virtual columns -4*HL..-1
     const int L1 = (sw - 1 - XS) >> 2, j1 = (sw - 1 - XS) & 3;  // lane / byte of column sw-1
-    const bool right_edge = L1 <= 63;              // some lane of the wave holds columns >= sw
-    const bool gray_dword = o.gray && (o.gray_stride & 3) == 0 && c0 + 3 < sw;
+    const bool right_edge = EDGE && L1 <= 63;      // some lane of the wave holds columns >= sw
+    const bool gray_dword = o.gray && (o.gray_stride & 3) == 0 && (!EDGE || c0 + 3 < sw);
     // reflected source columns of the lanes that straddle an image edge (BORDER_REFLECT_101)
     int xr0 = 0, xr1 = 0, xr2 = 0, xr3 = 0;
     if (needed && !fast) {
@@ -155,9 +157,9 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     const unsigned out_off = out_lane ? (unsigned)c0 : 0u;
     const unsigned rmask = lane == 63 - HR ? 1u : 3u;   // the last output lane's x+2 bit (row above) is not computed
     unsigned colmask = 0;  // which of the lane's 4 columns lie inside cvFindContours' zeroed frame
-    for (int j = 0; j < 4; j++) colmask |= (c0 + j >= 1 && c0 + j <= sw - 2) ? (1u << j) : 0u;
+    for (int j = 0; j < 4; j++) colmask |= (!EDGE || (c0 + j >= 1 && c0 + j <= sw - 2)) ? (1u << j) : 0u;
     unsigned pxsel = 0;    // bits j and 8+j: the lane's pixel j is an output pixel of this strip (outer / hole start nibbles)
-    for (int j = 0; j < 4; j++) pxsel |= (out_lane && c0 + j < sw) ? (0x101u << j) : 0u;
+    for (int j = 0; j < 4; j++) pxsel |= (out_lane && (!EDGE || c0 + j < sw)) ? (0x101u << j) : 0u;
 
     // Mask rows are collected in LDS, 8 rows at a time, and written as whole 16x8-pixel tiles (128 contiguous bytes, 32
     // per lane) -- a row at a time would be 16-byte pieces of 15 different cache lines per wave, and on this hardware a
@@ -459,7 +461,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     o.n_cands = ws.counters + CNT_FRAME_CANDS;
     o.cap_cands = ws.cap_frame_cands;
     o.err = ws.counters + CNT_ERR;
-    march_unit<true>(bgr + (size_t)f * frame_stride, row_stride, ws.sw, ws.sh, strip, Y0, Y1, o, stage[wave_uniform((int)(threadIdx.x >> 6))], rowbuf[wave_uniform((int)(threadIdx.x >> 6))], tab);
+    const int w4 = wave_uniform((int)(threadIdx.x >> 6));
+    const bool edge = strip == 0 || ((ws.sw - 1 - (strip * MARCH_STRIP - 4 * MARCH_HALO_L)) >> 2) <= 63;   // march_unit's left_edge || right_edge
+    if (edge) march_unit<true, true>(bgr + (size_t)f * frame_stride, row_stride, ws.sw, ws.sh, strip, Y0, Y1, o, stage[w4], rowbuf[w4], tab);
+    else march_unit<true, false>(bgr + (size_t)f * frame_stride, row_stride, ws.sw, ws.sh, strip, Y0, Y1, o, stage[w4], rowbuf[w4], tab);
 }
 
 // Odd width / height: the last column / row lies outside the even working size (opencvar.cpp:158) but is still
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         o.n_cands = ws.counters + CNT_CROP_CANDS;
         o.cap_cands = ws.cap_crop_cands;
         o.err = ws.counters + CNT_ERR;
-        march_unit<false>(src, ws.W, r.sw, r.sh, td.x0, td.y0, Y1, o, stage[wave], rowbuf[wave], tab);
+        march_unit<false, true>(src, ws.W, r.sw, r.sh, td.x0, td.y0, Y1, o, stage[wave], rowbuf[wave], tab);
     }
 }
 
