@@ -123,7 +123,7 @@ extern "C" int ocvar_hip_create_ex(OcvarHip** out, int device, int max_width, in
     // follower grids (and their slabs) scale with the batch: a one-frame context (the reference's per-frame call) does not
     // need -- or pay for -- the 512 + 1024 workgroups that keep a 2048-frame batch busy
     w.max_mid_blocks = (int)std::min<size_t>(MID_BLOCKS_MAX, std::max<size_t>(32, B));
-    w.max_long_blocks = (int)std::min<size_t>(LONG_BLOCKS_MAX, std::max<size_t>(32, B * 8));
+    w.max_long_blocks = (int)std::min<size_t>(LONG_BLOCKS_MAX, std::max<size_t>(128, B * 8));
     if ((rc = dev_alloc(c, &w.slab, (size_t)w.max_mid_blocks * 256 * SLAB_STRIDE))) return rc;
     if ((rc = dev_alloc(c, &w.slab3, (size_t)w.max_long_blocks * 4 * SLAB3_STRIDE))) return rc;
     w.cap_long = (int)std::min<size_t>(std::max<size_t>(B * 4096, (size_t)1 << 18), (size_t)1 << 28);   // survivors of tier 1 / tier 2: a noise frame has ~10^4
@@ -245,7 +245,11 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     w.sh = height & ~1;
     w.ns = (w.sw + 15) & ~15;
     w.n_frames = n_frames;
-    w.mid_steps = std::getenv("OCVAR_MID_STEPS") ? std::atoi(std::getenv("OCVAR_MID_STEPS")) : MID_STEPS;
+    // Tier 2's step budget: a batch of a few frames has too few borders to fill the GPU with one-lane walks, and its
+    // duration is then the longest walk (~800 one-microsecond steps around a crop) -- such batches hand everything longer
+    // than 128 steps to the wave tier, which crosses straight runs 64 pixels at a time (1080p, one frame per call: 3.2 ->
+    // 2.5 ms).  Large batches keep the long budget: there the one-lane walks are what fills the machine.
+    w.mid_steps = std::getenv("OCVAR_MID_STEPS") ? std::atoi(std::getenv("OCVAR_MID_STEPS")) : (n_frames <= 8 ? 128 : MID_STEPS);
     w.mid_blocks = std::getenv("OCVAR_MID_BLOCKS") ? std::atoi(std::getenv("OCVAR_MID_BLOCKS")) : w.max_mid_blocks;
     if (w.mid_blocks < 1 || w.mid_blocks > w.max_mid_blocks) w.mid_blocks = w.max_mid_blocks;
     w.long_blocks = std::getenv("OCVAR_LONG_BLOCKS") ? std::atoi(std::getenv("OCVAR_LONG_BLOCKS")) : w.max_long_blocks;
