@@ -230,3 +230,35 @@ def test_registration_of_a_frame_with_hundreds_of_squares():
         assert markers[0, k]["templateId"] == r.templateId and markers[0, k]["markerId"] == r.markerId
         gm = np.array(r.glMatrix)
         assert np.abs(markers[0, k]["glMatrix"] - gm).max() <= 1e-4 * max(1.0, np.abs(gm).max())
+
+
+def test_small_frames_in_heap_blocks_never_reach_the_device_directly():
+    """Small batches of small frames live in malloc'ed heap blocks that share their pages with other data; a randomised
+    sweep once faulted the GPU on such a host address while it was page-locked in place.  Batches below 8 MB and the
+    previous-marker arrays now travel through the context's own page-locked buffers: many odd-sized stateful calls,
+    results against the oracle."""
+    import opencv_ar_amd as oa
+    from opencv_ar_amd.tracking import StreamTracker
+    rng = np.random.default_rng(9)
+    cfg = H.synth_config(3, width=96, height=64, grid_x=1, grid_y=1, side_min=40, side_max=50)
+    names = ["2x2-01"]
+    tpls, cam = H.oracle_templates(names), H.oracle_camera(96, 64)
+    keep = []
+    for trial in range(24):
+        nb = int(rng.integers(2, 5))
+        keep.append(np.zeros(int(rng.integers(1, 40000)), np.uint8))   # shifts where the next arrays land in the heap
+        det = oa.Detector(96, 64, max_batch=nb)
+        det.set_templates([oa.Template.from_buffer_copy(bytes(t)) for t in tpls])
+        det.set_camera(oa.Camera.from_buffer_copy(bytes(cam)))
+        tracker = StreamTracker(det, nb)
+        frames = np.ascontiguousarray(np.stack([H.synth_frame(cfg, int(rng.integers(0, 1000)), names)[0] for _ in range(nb)]))
+        prev = [None] * nb
+        for step in range(2):
+            markers, counts = tracker.step(frames.copy())
+            for f in range(nb):
+                ref_m, _, _ = H.oracle_registration(frames[f], tpls, cam, prev=prev[f])
+                assert counts[f] == len(ref_m)
+                for k, r in enumerate(ref_m):
+                    assert markers[f, k]["markerId"] == r.markerId and markers[f, k]["templateId"] == r.templateId
+                prev[f] = ref_m
+        det.close()
