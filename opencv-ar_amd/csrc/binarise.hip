@@ -8,9 +8,13 @@
 // "Wave march": one 64-lane wavefront owns a strip of 256 columns (4 pixels per lane: 240 output columns + an
 // 8-column halo on each side) and walks down a chunk of rows.  Everything vertical lives in registers as
 // sliding windows (5 rows of the horizontal pyrDown sums, 3 rows of the horizontally up-sampled pyramid,
-// 7 rows of the horizontal Gaussian sums, 3 rows of threshold bits); everything horizontal is a 4-pixel packed
-// word handed to the neighbour lane.  No LDS allocation, no workgroup barrier, one coalesced dword load/store
-// per lane per row and plane.  HBM traffic per pixel: 3 B read + 1 B grey + 1 B mask (frame mode).
+// 8 pyrUp rows as one byte per row in two registers per pixel, the table outputs of the last two threshold rows);
+// everything horizontal is a 4-pixel packed word handed to the neighbour lane with a DPP wave shift.  One (unaligned)
+// load per lane and row, reflected columns included; the image itself never goes through LDS, which only holds a
+// 128-entry table (threshold-bit window -> neighbour-mask contributions and border-start nibbles), 8 mask rows per
+// wave on their way to whole 16x8 tiles, and the staged border starts.  The row body exists in several instances
+// (steady rows in odd/even pairs, strips away from the image edges) so that the hot loop carries no range tests.
+// HBM traffic per pixel: 3 B read + 1 B grey + 1 B mask (frame mode).
 // The arithmetic is the integer arithmetic of the definition, so the output is bit-identical:
 //   pyrDown  [1 4 6 4 1]^2, (v+128)>>8, BORDER_REFLECT_101        pyrUp  [1 6 1]/[4 4], (v+32)>>6, borders -1->1, n->n-1
 //   Gaussian [8 28 56 72 56 28 8]^2, (v+32768)>>16, BORDER_REPLICATE    threshold  src - mean > -8

@@ -15,7 +15,7 @@ constexpr int MARCH_HALO_L = 2, MARCH_HALO_R = 2;   // halo lanes (4 pixels each
 constexpr int MARCH_STRIP = 4 * (64 - MARCH_HALO_L - MARCH_HALO_R);   // 240 output columns of one wave's strip in the binarise kernel (256 loaded)
 constexpr int MARCH_CROP_ROWS = 256;       // rows per work unit in the crop pass (even)
 constexpr int MARCH_STAGE = 512;           // border starts a wave stages in LDS between two appends to the global list
-constexpr int BACK_STEPS = 32;
+constexpr int BACK_STEPS = 32;             // backward look of an outer start before it follows its border
 constexpr int PRE_STEPS = 8;               // steps every plausible start gets before it may queue for tier 1's full budget
 constexpr int SHORT_STEPS = 96;            // step budget of follower tier 1 (every plausible start, one lane each)
 constexpr int MID_STEPS = 1536;            // step budget of tier 2 (borders that outlived tier 1, one lane each); the rest: tier 3, one wave each
@@ -25,7 +25,7 @@ constexpr int MID_BLOCKS_MAX = 1024;       // tier-2 grid limit (x256 threads, o
 constexpr int SLAB3_PTS = 8192;            // points a tier-3 wave can keep in its slab
 constexpr int SLAB3_STRIDE = SLAB3_PTS + 64;   // dwords per tier-3 wave slab
 constexpr int LONG_BLOCKS_MAX = 1024;      // tier-3 grid limit (x4 waves, one slab each)
-constexpr int TILE = 64;                   // side of the LDS tile the wave-per-border follower walks in             // backward look of an outer start before it follows its border
+constexpr int TILE = 64;                   // side of the LDS tile the wave-per-border follower walks in
 
 // error bits accumulated in Workspace::err[0]
 enum { ERR_CAND_OVERFLOW = 1, ERR_POOL_OVERFLOW = 2, ERR_QUAD_OVERFLOW = 4, ERR_TRACE_OVERRUN = 8, ERR_CROP_OVERFLOW = 16,
