@@ -121,7 +121,8 @@ int ocvar_hip_debug_calibrate(OcvarHip* ctx, size_t bytes);
 int ocvar_hip_stage_ms(OcvarHip* ctx, float* ms, int n);
 /* Work counters of the last batch: [0] frame start candidates [1] crop ROIs [2] crop tiles
  * [3] crop start candidates [4] sum of crop areas (pixels) [5] point-pool ints used [6],[7] starts handed to follower
- * tier 2 (frames, crops) [8],[9] borders handed to tier 3 (frames, crops). */
+ * tier 2 (frames, crops) [8],[9] borders handed to tier 3 (frames, crops) [10]..[41] profiling slots of builds made with
+ * -DOCVAR_PROF (tools/prof_tier2.py), zero in the product build. */
 int ocvar_hip_counters(OcvarHip* ctx, long long* out, int n);
 
 #ifdef __cplusplus

@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-HIP_LIB = os.path.join(LIB_DIR, "libocvar_hip.so")
+HIP_LIB = os.environ.get("OCVAR_HIP_LIB") or os.path.join(LIB_DIR, "libocvar_hip.so")   # (override: instrumented builds of tools/prof_tier2.py)
 SYNTH_LIB = os.path.join(LIB_DIR, "libocvar_synth.so")
 HOST_LIB = os.path.join(LIB_DIR, "libopencv-ar.so.1.0.0")
 
@@ -273,7 +273,8 @@ class Detector:
         k = self._lib.ocvar_hip_stage_ms(self._ctx, _ptr(ms), 12)
         return ms[:max(k, 0)]
 
-    def counters(self):
-        out = np.zeros(10, np.int64)
-        k = self._lib.ocvar_hip_counters(self._ctx, _ptr(out), 10)
+    def counters(self, n=10):
+        """work counters of the last batch (n = 42 adds the profiling slots of a -DOCVAR_PROF build)"""
+        out = np.zeros(n, np.int64)
+        k = self._lib.ocvar_hip_counters(self._ctx, _ptr(out), n)
         return out[:max(k, 0)]

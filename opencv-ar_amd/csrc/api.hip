@@ -141,6 +141,7 @@ extern "C" int ocvar_hip_create_ex(OcvarHip** out, int device, int max_width, in
     if ((rc = dev_alloc(c, &w.tiles_crop, (size_t)w.cap_crop_tiles))) return rc;
     if ((rc = dev_alloc(c, &w.quads_crop, (size_t)w.cap_crop_quads))) return rc;
     if ((rc = dev_alloc(c, &w.best_crop, (size_t)w.cap_crop_rois))) return rc;
+    if ((rc = dev_alloc(c, &w.crop_min_rest, (size_t)w.cap_crop_rois))) return rc;
     if ((rc = dev_alloc(c, &w.cand_recs, B * max_quads * MAXT))) return rc;
     if ((rc = dev_alloc(c, &w.prev, B * MAXM))) return rc;
     if ((rc = dev_alloc(c, &w.n_prev, B))) return rc;
@@ -299,7 +300,14 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     launch_binarise_frames(w, d_bgr, row_stride, frame_stride, grey_in_place, s);
     TRACE_LAUNCH("binarise_frames", s);
+    // Timing experiments (results are then incomplete or wrong; never set in production):
+    //   OCVAR_ONLY_BINARISE=1        stop after the first kernel (tools/binarise_only.py)
+    //   OCVAR_SKIP_CROP_KERNELS=bits knock out kernels of the crop pass: 1 binarise_crops, 2 tier 1, 4 tier 2, 8 tier 3
+    static const bool only_binarise = std::getenv("OCVAR_ONLY_BINARISE") != nullptr;
+    static const int skip_crop = std::getenv("OCVAR_SKIP_CROP_KERNELS") ? std::atoi(std::getenv("OCVAR_SKIP_CROP_KERNELS")) : 0;
+    if (only_binarise) stages = 0;
     HIP_TRY(c, hop(1, s, f));
+    if (stages > 0) {
     launch_follow_frames(w, f);
     TRACE_LAUNCH("follow tier 1 (frames)", f);
     HIP_TRY(c, hipEventRecord(c->ev[2], f));
@@ -311,18 +319,21 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     HIP_TRY(c, hipEventRecord(c->ev[4], f));
     launch_order_and_crops(w, f);
     TRACE_LAUNCH("order_and_crops", f);
+    } else {
+        for (int k = 2; k < 5; k++) HIP_TRY(c, hipEventRecord(c->ev[k], f));
+    }
     if (stages > 2) {
         HIP_TRY(c, hop(5, f, s));
-        launch_binarise_crops(w, s);
+        if (!(skip_crop & 1)) launch_binarise_crops(w, s);
         TRACE_LAUNCH("binarise_crops", s);
         HIP_TRY(c, hop(6, s, f));
-        launch_follow_crops(w, f);
+        if (!(skip_crop & 2)) launch_follow_crops(w, f);
         TRACE_LAUNCH("follow tier 1 (crops)", f);
         HIP_TRY(c, hipEventRecord(c->ev[7], f));
-        launch_follow_mid_crops(w, f);
+        if (!(skip_crop & 4)) launch_follow_mid_crops(w, f);
         TRACE_LAUNCH("follow tier 2 (crops)", f);
         HIP_TRY(c, hipEventRecord(c->ev[8], f));
-        launch_follow_long_crops(w, f);
+        if (!(skip_crop & 8)) launch_follow_long_crops(w, f);
         TRACE_LAUNCH("follow tier 3 (crops)", f);
         HIP_TRY(c, hipEventRecord(c->ev[9], f));
         launch_decode(w, f);
@@ -667,5 +678,7 @@ extern "C" int ocvar_hip_counters(OcvarHip* c, long long* out, int n) {
                       h[CNT_MID_F], h[CNT_MID_C], h[CNT_LONG_F], h[CNT_LONG_C]};
     int k = 0;
     for (; k < 10 && k < n; k++) out[k] = v[k];
+    // values 10..41: profiling slots (zero unless the library was built with -DOCVAR_PROF)
+    for (; k < 42 && k < n; k++) out[k] = (long long)reinterpret_cast<const unsigned long long*>(h + CNT_PROF)[k - 10];
     return k;
 }

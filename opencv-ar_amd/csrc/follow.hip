@@ -36,6 +36,21 @@ __device__ __forceinline__ unsigned long long uni(unsigned long long v) {
 }
 __device__ __forceinline__ double uni(double v) { return __longlong_as_double((long long)uni((unsigned long long)__double_as_longlong(v))); }
 
+// Profiling build (-DOCVAR_PROF, `make prof`): every tier-2 wave accumulates cycle counts (s_memtime) and event counts and
+// adds them once, at its end, to the 64-bit slots at counters + CNT_PROF (read back through ocvar_hip_counters, values
+// 10..41; tools/prof_tier2.py).  Compiled out of the product build.
+#ifdef OCVAR_PROF
+#define PROF_NOW() __builtin_readcyclecounter()
+#define PROF_DECL() unsigned long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_ADD(slot, v) do { prof_acc[slot] += (unsigned long long)(v); } while (0)
+#define PROF_FLUSH(base) do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; i_++) if (i_ != 7) atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_PROF) + (base) + i_, prof_acc[i_]); } while (0)
+#else
+#define PROF_NOW() 0ull
+#define PROF_DECL() do { } while (0)
+#define PROF_ADD(slot, v) do { (void)(v); } while (0)
+#define PROF_FLUSH(base) do { } while (0)
+#endif
+
 // geometry of the ROI a start belongs to
 struct PlaneRef {
     const uint8_t* nbr;
@@ -382,6 +397,9 @@ __device__ __forceinline__ bool wave_finish_packed(const Workspace& ws, const St
         per += (double)sqrt_rn(dx * dx + dy * dy);
     }
     per = wave_sum_f64(per);
+#ifdef OCVAR_PROF
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_PROF) + (CROP ? 16 : 0) + 7, 1ull);
+#endif
     const bool k32 = npts <= 1024 && (long long)bw * bw + (long long)bh * bh < (1ll << 21);
     const int m = k32 ? wave_approx_dp<true>(src, npts, per * 0.02, sc->dst, sc->stack) : wave_approx_dp<false>(src, npts, per * 0.02, sc->dst, sc->stack);
     if (m != 4) return false;
@@ -391,6 +409,57 @@ __device__ __forceinline__ bool wave_finish_packed(const Workspace& ws, const St
     if (!quad_filter(q, pl.img_w, pl.img_h)) return false;
     if (lane == 0) emit_quad<CROP>(ws, c, q);
     return true;
+}
+
+// trace_core.h::run_has_earlier_pixel on the tiled mask plane: the masks of the run's pixels lie next to each other in a
+// tile row, so the 16 pixels from the start on come with two 16-byte loads (the tile row the start is in and the same
+// row of the next tile) instead of one byte load per pixel -- a quarter of the requests for twice the look-ahead, which
+// matters on shallow staircases, where the row above reaches over the run only after more than 8 pixels.  The per-pixel
+// tests become byte-parallel bit scans.  Same decision rule: pixel k's row above is looked at before its E neighbour; a
+// run that is still going on after the look-ahead (or at the plane's edge) is given the benefit of the doubt.
+__device__ __forceinline__ bool run_has_earlier_pixel_rows(const uint8_t* nbr, int ns, int cpos, int is_hole) {
+    const int x = cpos % ns, y = cpos / ns;
+    const int xa = x & ~15;
+    const uint8_t* row = nbr + nbr_addr(xa, y, ns);   // 16 masks of tile row (xa .. xa+15, y): 16-byte aligned
+    const uint4 A = *reinterpret_cast<const uint4*>(row);
+    uint4 B = make_uint4(0u, 0u, 0u, 0u);
+    if (xa + 16 < ns) B = *reinterpret_cast<const uint4*>(row + 128);   // the next tile of the same tile row
+    // the 16 masks from pixel x on: bytes (x & 15) .. of A:B
+    const unsigned w[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
+    const int ds = (x & 15) >> 2;
+    const unsigned bs = (unsigned)(x & 3);
+    unsigned m[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {   // ds is 0..3: select without dynamic indexing
+            lo = ds == j ? w[i + j] : lo;
+            hi = ds == j ? w[i + j + 1 < 8 ? i + j + 1 : 7] : hi;
+        }
+        m[i] = __builtin_amdgcn_alignbyte(hi, lo, bs);
+    }
+    int lim = ns - x < 16 ? ns - x : 16;   // pixels that exist
+    unsigned long long bad, end;
+    const unsigned long long m0 = ((unsigned long long)m[1] << 32) | m[0], m1 = ((unsigned long long)m[3] << 32) | m[2];
+    for (int half = 0; half < 2; half++) {
+        const unsigned long long v = half ? m1 : m0;
+        const int n = lim - 8 * half;
+        if (n <= 0) return false;
+        const unsigned long long keep = n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1ull);
+        if (is_hole) {
+            bad = ~v & 0x0404040404040404ull & keep;   // background directly above a pixel of the background run
+            end = v & 0x0101010101010101ull & keep;    // E is foreground: the run ends here
+        } else {
+            bad = v & 0x0e0e0e0e0e0e0e0eull & keep;    // NE, N or NW of a pixel of the foreground run is foreground
+            end = ~v & 0x0101010101010101ull & keep;   // E is background: the run ends here
+        }
+        if (bad | end) {
+            const int kb = bad ? __builtin_ctzll(bad) >> 3 : 64, ke = end ? __builtin_ctzll(end) >> 3 : 64;
+            return kb <= ke;
+        }
+    }
+    return false;
 }
 
 // Tier 1, one lane per start, mask bytes read from global memory (one memory latency per step, 64 starts per wave in
@@ -407,7 +476,7 @@ __device__ __forceinline__ int follow_short(const Workspace& ws, const StartCand
         // budget or still running: tier 2, which follows again with point storage -- or straight to the wave tier when
         // the border barely turned in SHORT_STEPS steps (an image-sized straight border would only burn tier 2's whole
         // budget before getting there anyway).
-        if (!c.is_hole && earlier_start_behind(pl.nbr, pl.ns, pl.plane, c.pos, 0, BACK_STEPS)) return 0;
+        if (earlier_start_behind(pl.nbr, pl.ns, pl.plane, c.pos, c.is_hole, BACK_STEPS)) return 0;
         // crops: no border of a crop is longer than tier 2's budget by much (the crop's own frame border is ~4 sides of
         // <= 260 pixels), so the probe would only repeat what tier 2 does anyway.  A border that starts on the inner edge
         // of the crop's zeroed frame is (nearly always) the background's own outer border, ~800 steps around the crop: the
@@ -524,7 +593,7 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
             if (idx < tk_end) {
                 cc = cands[idx];
                 const PlaneRef pl = plane_of<CROP>(ws, cc.roi);
-                if (cc.pos > 0 && cc.pos < pl.plane && !run_has_earlier_pixel(pl.nbr, pl.ns, cc.pos, cc.is_hole, 8))
+                if (cc.pos > 0 && cc.pos < pl.plane && !run_has_earlier_pixel_rows(pl.nbr, pl.ns, cc.pos, cc.is_hole))
                     alive = trace_flat(pl.nbr, pl.ns, pl.plane, cc.pos, cc.is_hole, nullptr, 0, PRE_STEPS).status == TRACE_OVERRUN;
             }
             const unsigned long long mask = __ballot(alive);
@@ -542,6 +611,7 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
             route = follow_short<CROP>(ws, c);
         }
         queued -= take;
+        if (CROP && route == 1) atomicMin(ws.crop_min_rest + c.roi, c.pos);   // tier 2 walks a crop's earliest start first (see follow_mid_kernel)
         collect(0, o_n0, route == 1, c);
         collect(1, o_n1, route == 2, c);
         if (CROP) collect(2, o_n2, route == 3, c);
@@ -566,19 +636,26 @@ constexpr int POINT_ROW = MID_BLOCK + 1;
 constexpr int FLUSH_W = MID_BLOCK <= 16 ? 16 : 32;   // lanes that carry one walk's parked points in a flush (>= MID_BLOCK)
 static_assert(FLUSH_W >= MID_BLOCK && 64 % FLUSH_W == 0, "a group of lanes covers a whole row of parked points");
 
+// Crops, exact pruning: of a crop's quads only the one that starts earliest is used (cvarGetSquare keeps the sequence's last
+// quad, opencvar.cpp:401-430), so a border that starts after a quad the crop already has can never matter -- it is not
+// walked, and a walked one is not approximated.  To have that quad early, a crop's borders are walked in two launches:
+// phase 1 takes the starts on the crop's frame (nearly always the background's own border: the earliest start, rarely a
+// valid quad) and each crop's earliest other start (nearly always the marker's outline: the quad that wins); phase 2 takes
+// what is left and skips every start behind its crop's best quad -- the outline's other side, the code cells, and the
+// staircase starts inside them: about half of a crop's steps.  Frames keep all their quads: one launch, phase 0.
 template <bool CROP>
-__global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
+__global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws, int phase) {
     __shared__ WaveScratch scratch[4];
     __shared__ unsigned parked[4][64 * POINT_ROW];
     const StartCand* cands = CROP ? ws.mid_crop : ws.mid_frame;
     StartCand* longs = CROP ? ws.long_crop : ws.long_frame;
     int n = ws.counters[CROP ? CNT_MID_C : CNT_MID_F];
     if (n > ws.cap_long) n = ws.cap_long;
-    // crops: the starts tier 1 expects to be the longest walks come first in the ticket order
-    int n_first = CROP ? ws.counters[CNT_MID_C_FIRST] : 0;
+    // crops, phase 1: the starts on the crop frames (the longest walks) come first in the ticket order
+    int n_first = (CROP && phase == 1) ? ws.counters[CNT_MID_C_FIRST] : 0;
     if (n_first > ws.cap_long) n_first = ws.cap_long;
     n += n_first;
-    int* ticket = ws.counters + (CROP ? CNT_TICKET_MC : CNT_TICKET_MF);
+    int* ticket = ws.counters + (CROP ? (phase == 2 ? CNT_TICKET_MC2 : CNT_TICKET_MC) : CNT_TICKET_MF);
     int* n_long = ws.counters + (CROP ? CNT_LONG_C : CNT_LONG_F);
     const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6));
@@ -597,7 +674,8 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
     FlatWalk w;
     w.status = TRACE_NOT_FIRST;
     // every round hands out at least one start or retires at least one walk after <= budget / MID_BLOCK rounds of stepping
-    long long guard = ((long long)n + 64) * (budget / MID_BLOCK + 4) + 64;
+    long long guard = ((long long)n + 64) * (budget / MID_BLOCK + 5) + 64;
+    PROF_DECL();
     for (;;) {
         if (--guard < 0) {
             if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TICKET_RUNAWAY);
@@ -605,8 +683,13 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
         }
         // hand idle lanes the next starts of the list (one ticket fetch for all of them; taking list entries in bulk per wave
         // instead was slower: lanes wait for the next round whenever the wave's range runs out, and the ranges unbalance the tail)
-        const unsigned long long idle = __ballot(!have);
-        if (more && idle) {
+        const unsigned long long pt0 = PROF_NOW();
+        // (crops: a start may be skipped -- not this phase's, or behind its crop's best quad -- so idle lanes get up to four
+        // hand-outs per round; every hand-out consumes list entries, which the guard counts)
+        for (int tries = 0; tries < (CROP ? 4 : 1); tries++) {
+            const unsigned long long idle = __ballot(!have);
+            if (!(more && idle)) break;
+            if (tries > 0) --guard;
             const int cnt = __popcll(idle);
             int base = 0;
             if (ticket_lane() == 0) base = atomicAdd(ticket, cnt);
@@ -616,8 +699,14 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
                 const int idx = base + __popcll(idle & below);
                 if (idx < n) {
                     c = (CROP && idx < n_first) ? ws.mid_first_crop[idx] : cands[idx - n_first];
+                    bool take = true;
+                    if (CROP) {
+                        const int earliest = ws.crop_min_rest[c.roi];
+                        if (phase == 1) take = idx < n_first || c.pos == earliest;
+                        else take = c.pos != earliest && !((unsigned)(ws.best_crop[c.roi] >> 32) < (unsigned)c.pos);
+                    }
                     pl = plane_of<CROP>(ws, c.roi);
-                    if (c.pos > 0 && c.pos < pl.plane) {
+                    if (take && c.pos > 0 && c.pos < pl.plane) {
                         flat_begin(w, pl.nbr, pl.ns, c.pos, c.is_hole);
                         have = true;
                         flushed = 0;
@@ -626,9 +715,13 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
             }
         }
         if (__ballot(have) == 0) break;
+        const unsigned long long pt1 = PROF_NOW();
+        PROF_ADD(0, pt1 - pt0);
         for (int k = 0; k < MID_BLOCK; k++) {
             const bool running = have && w.status < 0;
             if (__ballot(running) == 0) break;
+            PROF_ADD(4, 1);
+            PROF_ADD(5, __popcll(__ballot(running)));
             if (running)
                 flat_step_t<false>(w, pl.nbr, pl.ns, pl.plane, c.pos, budget, [&](bool emit, int x, int y) {
                     my_row[(emit && w.npts < SLAB_PTS) ? w.npts - flushed : MID_BLOCK] = (unsigned)x | ((unsigned)y << 16);
@@ -637,6 +730,8 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
         // the step budget is checked here, once per block, instead of in every step (a walk may overshoot it by up to
         // MID_BLOCK - 1 steps; it is handed to the wave tier either way, which follows the border again from its start)
         if (have && w.status < 0 && w.step >= budget) w.status = TRACE_OVERRUN;
+        const unsigned long long pt2 = PROF_NOW();
+        PROF_ADD(1, pt2 - pt1);
         {   // append the parked points to the slabs: every group of FLUSH_W lanes carries one walk's row per store
             const int stored = w.npts < SLAB_PTS ? w.npts : SLAB_PTS;
             const int pend = have ? stored - flushed : 0;
@@ -659,8 +754,29 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
             }
             flushed += pend;
         }
+        const unsigned long long pt3 = PROF_NOW();
+        PROF_ADD(2, pt3 - pt2);
         // retire the walks that have ended
         int route = 0, slab_npts = 0;
+#ifdef OCVAR_PROF
+        {   // where the steps went: walks that were not their border's first position / closed borders / budget exhausted
+            const bool done = have && w.status >= 0;
+            for (int st_ = 0; st_ < 3; st_++) {
+                const int want = st_ == 0 ? (int)TRACE_NOT_FIRST : st_ == 1 ? (int)TRACE_OK : (int)TRACE_OVERRUN;
+                const bool mine = done && w.status == want;
+                PROF_ADD(9 + 2 * st_, __popcll(__ballot(mine)));
+                unsigned steps_ = mine ? (unsigned)w.step : 0u;
+                for (int o_ = 32; o_ > 0; o_ >>= 1) steps_ += (unsigned)__shfl_xor((int)steps_, o_, 64);
+                PROF_ADD(8 + 2 * st_, steps_);
+            }
+            bool useless = false;   // crops: a closed border that starts after the crop's best quad so far
+            if (CROP && done && w.status == TRACE_OK) useless = (unsigned)(ws.best_crop[c.roi] >> 32) < (unsigned)c.pos;
+            unsigned us_ = useless ? (unsigned)w.step : 0u;
+            for (int o_ = 32; o_ > 0; o_ >>= 1) us_ += (unsigned)__shfl_xor((int)us_, o_, 64);
+            PROF_ADD(14, us_);
+            PROF_ADD(15, __popcll(__ballot(done && w.status == TRACE_OK && w.npts < 4)));
+        }
+#endif
         if (have && w.status >= 0) {
             if (w.status == TRACE_OVERRUN) route = 1;   // budget exhausted: a longer border (tier 3)
             else if (w.status == TRACE_OK && w.npts >= 4) {
@@ -686,8 +802,12 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
             const int nl = __builtin_amdgcn_readlane(slab_npts, L);
             const unsigned* sl = wave_slabs + (size_t)L * SLAB_STRIDE;
             const PlaneRef pll = plane_of<CROP>(ws, cl.roi);
-            wave_finish_packed<CROP, true>(ws, cl, pll, sl, nl, parked[wave], &scratch[wave]);
+            // crops: a border that starts behind the crop's best quad cannot replace it
+            const bool beaten = CROP && uni((unsigned)(ws.best_crop[cl.roi] >> 32)) < (unsigned)cl.pos;
+            if (!beaten) wave_finish_packed<CROP, true>(ws, cl, pll, sl, nl, parked[wave], &scratch[wave]);
+            PROF_ADD(6, 1);
         }
+        PROF_ADD(3, PROF_NOW() - pt3);
         // budget exhausted: queue for the wave tier
         const unsigned long long mask = __ballot(route == 1);
         if (mask) {
@@ -702,6 +822,7 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws) {
             }
         }
     }
+    PROF_FLUSH(CROP ? 16 : 0);
 }
 
 // ---- Phase B: one wave per long border, walking inside an LDS tile cache -------------------------------------
@@ -904,13 +1025,20 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
         c.pos = uni(c.pos);
         c.is_hole = uni(c.is_hole);
         const PlaneRef pl = plane_of<CROP>(ws, c.roi);
+        // crops: a border that starts behind the crop's best quad cannot replace it (see follow_mid_kernel); nothing below
+        // depends on lt then (status TRACE_NOT_FIRST: dropped)
+        const bool beaten = CROP && uni((unsigned)(ws.best_crop[c.roi] >> 32)) < (unsigned)c.pos;
         TileCache t;
         t.lds = tiles[wave];
         t.nbr = pl.nbr;
         t.ns = uni(pl.ns);
         t.sh = uni(pl.sh);
         t.tx0 = t.ty0 = -(1 << 28);
-        const LeanTrace lt = trace_lean_tiled(t, c.pos, c.is_hole, slab, SLAB3_PTS, 4 * uni(pl.plane) + 16);
+        LeanTrace lt;
+        lt.status = TRACE_NOT_FIRST;
+        lt.npts = 0;
+        lt.steps = 0;
+        if (!beaten) lt = trace_lean_tiled(t, c.pos, c.is_hole, slab, SLAB3_PTS, 4 * uni(pl.plane) + 16);
         // (no `continue` below: one back-edge, scalar conditions -- see uni())
         if (lt.status == TRACE_OVERRUN) {
             if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TRACE_OVERRUN);
@@ -1004,6 +1132,7 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
                     roi.owner = i; roi.nbr_off = off;
                     ws.rois_crop[r] = roi;
                     ws.best_crop[r] = ~0ull;
+                    ws.crop_min_rest[r] = 0x7fffffff;
                     for (int t = 0; t < ntx * nty; t++) {
                         TileDesc td;
                         td.roi = r; td.x0 = t % ntx; td.y0 = (t / ntx) * MARCH_CROP_ROWS;
@@ -1024,10 +1153,11 @@ void launch_follow_crops(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_kernel<true>, dim3(ws.short_blocks), dim3(256), 0, stream, ws);
 }
 void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(follow_mid_kernel<false>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL(follow_mid_kernel<false>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 0);
 }
 void launch_follow_mid_crops(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 1);
+    hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 2);
 }
 void launch_follow_long_frames(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_long_kernel<false>, dim3(ws.long_blocks), dim3(256), 0, stream, ws);

@@ -46,7 +46,8 @@ struct CandRec {   // pre-dedupe candidate, slot [frame][quad][template]
 enum { CNT_FRAME_CANDS = 0, CNT_CROP_ROIS = 1, CNT_CROP_TILES = 2, CNT_CROP_CANDS = 3,
        CNT_POOL_INTS = 4 /* 64-bit, uses 4..5 */, CNT_CROP_QUADS = 6, CNT_TICKET_F = 7, CNT_TICKET_C = 8, CNT_ERR = 9,
        CNT_CROP_PIXELS = 10 /* 64-bit, uses 10..11 */, CNT_LONG_F = 12, CNT_LONG_C = 13, CNT_TICKET_LF = 14, CNT_TICKET_LC = 15,
-       CNT_MID_F = 16, CNT_MID_C = 17, CNT_TICKET_MF = 18, CNT_TICKET_MC = 19, CNT_TICKET_BC = 20, CNT_MID_C_FIRST = 21, CNT_COUNT = 24 };
+       CNT_MID_F = 16, CNT_MID_C = 17, CNT_TICKET_MF = 18, CNT_TICKET_MC = 19, CNT_TICKET_BC = 20, CNT_MID_C_FIRST = 21, CNT_TICKET_MC2 = 22,
+       CNT_PROF = 24 /* 32 64-bit profiling slots, written only by builds with -DOCVAR_PROF (tools/prof_tier2.py) */, CNT_COUNT = 88 };
 
 struct Workspace {
     // limits
@@ -86,6 +87,7 @@ struct Workspace {
     unsigned long long* crop_pixels;   // = counters + CNT_CROP_PIXELS: running sum of crop plane sizes (pool cursor)
     QuadRec* quads_crop;    // pool
     unsigned long long* best_crop;     // [cap_crop_rois] (start<<32 | quad slot), ~0 = none
+    int* crop_min_rest;     // [cap_crop_rois] smallest start position among a crop's tier-2 starts off the crop's frame (tier 2 walks these first)
     CandRec* cand_recs;     // [B][maxq][MAXT]
     MarkerRec* prev;        // [B][MAXM]
     int* n_prev;            // [B]
@@ -105,7 +107,7 @@ void launch_binarise_crops(const Workspace& ws, hipStream_t stream);
 void launch_follow_frames(const Workspace& ws, hipStream_t stream);
 void launch_follow_crops(const Workspace& ws, hipStream_t stream);
 void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream);
-void launch_follow_mid_crops(const Workspace& ws, hipStream_t stream);
+void launch_follow_mid_crops(const Workspace& ws, hipStream_t stream);   // both phases
 void launch_follow_long_frames(const Workspace& ws, hipStream_t stream);
 void launch_follow_long_crops(const Workspace& ws, hipStream_t stream);
 void launch_order_and_crops(const Workspace& ws, hipStream_t stream);

@@ -458,13 +458,13 @@ OCVAR_HD bool earlier_start_behind(const uint8_t* nbr, int sw, int plane, int cp
 // of the run's pixels hold exactly these bits (NW N NE of each run pixel / N of each run pixel; E says whether the run
 // goes on), the loads are independent (one memory latency, usually one cache line), and on marker frames ~80 % of the
 // plausible starts (stair corners of slanted edges) end here.  The binarise kernel's local test is the first pixel of
-// this one.  max_run bounds the look-ahead; a run that is still going on after max_run pixels is given the benefit of
-// the doubt.
+// this one.  max_run (<= 16) bounds the look-ahead; a run that is still going on after max_run pixels is given the benefit
+// of the doubt.  (The device reads the 16 masks with two 16-byte loads: follow.hip::run_has_earlier_pixel_rows.)
 OCVAR_HD bool run_has_earlier_pixel(const uint8_t* nbr, int ns, int cpos, int is_hole, int max_run) {
     const int x = cpos % ns, y = cpos / ns;
-    unsigned m[8];
-    const int n = max_run < 8 ? max_run : 8;
-    for (int k = 0; k < 8; k++) m[k] = (k < n && x + k < ns) ? nbr[nbr_addr(x + k, y, ns)] : 0u;
+    unsigned m[16];
+    const int n = max_run < 16 ? max_run : 16;
+    for (int k = 0; k < 16; k++) m[k] = (k < n && x + k < ns) ? nbr[nbr_addr(x + k, y, ns)] : 0u;
     for (int k = 0; k < n && x + k < ns; k++) {
         if (is_hole) {
             if (!(m[k] & 0x04u)) return true;       // background directly above a pixel of the background run

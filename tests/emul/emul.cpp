@@ -53,8 +53,8 @@ extern "C" int emul_find_contours(const uint8_t* bin, int w, int h, int* pts, in
             bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1) && !(b(x + 1, y) && b(x + 2, y - 1));
             bool hole = !c && b(x - 1, y) && b(x, y - 1) && (b(x + 1, y) || b(x + 1, y - 1));
             if (!outer && !hole) continue;
-            if (g_run_filter && run_has_earlier_pixel(nbr.data(), w, y * w + x, hole ? 1 : 0, 8)) continue;
-            if (outer && g_back > 0 && earlier_start_behind(nbr.data(), w, w * h, y * w + x, 0, g_back)) { g_back_drops++; continue; }
+            if (g_run_filter && run_has_earlier_pixel(nbr.data(), w, y * w + x, hole ? 1 : 0, 16)) continue;
+            if (g_back > 0 && earlier_start_behind(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, g_back)) { g_back_drops++; continue; }
             TraceStats st;
             if (g_lean) {
                 LeanTrace lt = g_lean == 2 ? trace_flat(nbr.data(), w, w * h, y * w + x, hole ? 1 : 0, buf.data(), (int)buf.size() / 2 - 1, 4 * w * h + 16)
@@ -130,8 +130,8 @@ extern "C" int emul_find_squares_bin(const uint8_t* bin, int sw, int sh, int img
             bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1) && !(b(x + 1, y) && b(x + 2, y - 1));
             bool hole = !c && b(x - 1, y) && b(x, y - 1) && (b(x + 1, y) || b(x + 1, y - 1));
             if (!outer && !hole) continue;
-            if (g_run_filter && run_has_earlier_pixel(nbr.data(), sw, y * sw + x, hole ? 1 : 0, 8)) continue;
-            if (outer && g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, 0, g_back)) { g_back_drops++; continue; }
+            if (g_run_filter && run_has_earlier_pixel(nbr.data(), sw, y * sw + x, hole ? 1 : 0, 16)) continue;
+            if (g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, hole ? 1 : 0, g_back)) { g_back_drops++; continue; }
             st_[0]++;
             if (g_lean) {   // the tier-2/3 flow: store while following, statistics from the stored points
                 buf.resize(2 * 4097);
@@ -202,7 +202,7 @@ extern "C" int emul_candidate_steps(const uint8_t* bin, int sw, int sh, int* typ
             bool outer = c && !b(x - 1, y) && !b(x - 1, y - 1) && !b(x, y - 1) && !b(x + 1, y - 1) && !(b(x + 1, y) && b(x + 2, y - 1));
             bool hole = !c && b(x - 1, y) && b(x, y - 1) && (b(x + 1, y) || b(x + 1, y - 1));
             if (!outer && !hole) continue;
-            if (outer && g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, 0, g_back)) { g_back_drops++; continue; }
+            if (g_back > 0 && earlier_start_behind(nbr.data(), sw, sw * sh, y * sw + x, hole ? 1 : 0, g_back)) { g_back_drops++; continue; }
             TraceStats st = tb<false>(nbr.data(), sw, sw * sh, y * sw + x, hole, nullptr, 0, 4 * sw * sh + 16);
             int s = -1;
             if (st.status == TRACE_NOT_FIRST) {
