@@ -9,6 +9,7 @@
 // rectangle set-up of the candidate loop (676-693).
 #include "kernels.h"
 #include "trace_core.h"
+#include <cstdlib>
 
 namespace ocvar {
 
@@ -626,7 +627,10 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
 // most lanes would sit idle behind the longest border (a crop holds a ~900-step border next to 100-step ones).  Here a
 // lane whose walk has ended is retired every MID_BLOCK steps -- routed on, or approximated by the whole wave from its
 // slab -- and takes the next start from the list, so the lanes stay busy until the list is empty.
-constexpr int MID_BLOCK = 32;
+#ifndef OCVAR_MID_BLOCK
+#define OCVAR_MID_BLOCK 32
+#endif
+constexpr int MID_BLOCK = OCVAR_MID_BLOCK;
 // A walk's corner points are not stored to its slab step by step -- 64 lanes x one dword in 64 different cache lines per
 // step made the stores, not the dependent mask loads, the bulk of this kernel's time (1.7 of 2.8 ms per 2048 frames) --
 // but parked in LDS (row of POINT_ROW dwords per lane: up to MID_BLOCK points + the dummy slot of steps without a point;
@@ -636,6 +640,9 @@ constexpr int POINT_ROW = MID_BLOCK + 1;
 constexpr int FLUSH_W = MID_BLOCK <= 16 ? 16 : 32;   // lanes that carry one walk's parked points in a flush (>= MID_BLOCK)
 static_assert(FLUSH_W >= MID_BLOCK && 64 % FLUSH_W == 0, "a group of lanes covers a whole row of parked points");
 
+#ifndef OCVAR_MID_ATTR
+#define OCVAR_MID_ATTR
+#endif
 // Crops, exact pruning: of a crop's quads only the one that starts earliest is used (cvarGetSquare keeps the sequence's last
 // quad, opencvar.cpp:401-430), so a border that starts after a quad the crop already has can never matter -- it is not
 // walked, and a walked one is not approximated.  To have that quad early, a crop's borders are walked in two launches:
@@ -644,7 +651,7 @@ static_assert(FLUSH_W >= MID_BLOCK && 64 % FLUSH_W == 0, "a group of lanes cover
 // what is left and skips every start behind its crop's best quad -- the outline's other side, the code cells, and the
 // staircase starts inside them: about half of a crop's steps.  Frames keep all their quads: one launch, phase 0.
 template <bool CROP>
-__global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws, int phase) {
+__global__ __launch_bounds__(256) OCVAR_MID_ATTR void follow_mid_kernel(Workspace ws, int phase) {
     __shared__ WaveScratch scratch[4];
     __shared__ unsigned parked[4][64 * POINT_ROW];
     const StartCand* cands = CROP ? ws.mid_crop : ws.mid_frame;
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws, int phase
     int n = ws.counters[CROP ? CNT_MID_C : CNT_MID_F];
     if (n > ws.cap_long) n = ws.cap_long;
     // crops, phase 1: the starts on the crop frames (the longest walks) come first in the ticket order
-    int n_first = (CROP && phase == 1) ? ws.counters[CNT_MID_C_FIRST] : 0;
+    int n_first = (CROP && phase != 2) ? ws.counters[CNT_MID_C_FIRST] : 0;
     if (n_first > ws.cap_long) n_first = ws.cap_long;
     n += n_first;
     int* ticket = ws.counters + (CROP ? (phase == 2 ? CNT_TICKET_MC2 : CNT_TICKET_MC) : CNT_TICKET_MF);
@@ -702,8 +709,10 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws, int phase
                     bool take = true;
                     if (CROP) {
                         const int earliest = ws.crop_min_rest[c.roi];
+                        const bool beaten = (unsigned)(ws.best_crop[c.roi] >> 32) < (unsigned)c.pos;
                         if (phase == 1) take = idx < n_first || c.pos == earliest;
-                        else take = c.pos != earliest && !((unsigned)(ws.best_crop[c.roi] >> 32) < (unsigned)c.pos);
+                        else if (phase == 2) take = c.pos != earliest && !beaten;
+                        else take = !beaten;   // phase 0 on crops (OCVAR_CROP_PHASES=1): one launch, pruning only by what happens to be finished
                     }
                     pl = plane_of<CROP>(ws, c.roi);
                     if (take && c.pos > 0 && c.pos < pl.plane) {
@@ -1156,6 +1165,11 @@ void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_mid_kernel<false>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 0);
 }
 void launch_follow_mid_crops(const Workspace& ws, hipStream_t stream) {
+    static const bool one_phase = std::getenv("OCVAR_CROP_PHASES") && std::atoi(std::getenv("OCVAR_CROP_PHASES")) == 1;
+    if (one_phase) {
+        hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 0);
+        return;
+    }
     hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 1);
     hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 2);
 }
