@@ -305,6 +305,11 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     //   OCVAR_SKIP_CROP_KERNELS=bits knock out kernels of the crop pass: 1 binarise_crops, 2 tier 1, 4 tier 2, 8 tier 3
     static const bool only_binarise = std::getenv("OCVAR_ONLY_BINARISE") != nullptr;
     static const int skip_crop = std::getenv("OCVAR_SKIP_CROP_KERNELS") ? std::atoi(std::getenv("OCVAR_SKIP_CROP_KERNELS")) : 0;
+    if (only_binarise || skip_crop) {
+        static bool warned = false;
+        if (!warned) std::fprintf(stderr, "ocvar_hip: OCVAR_ONLY_BINARISE / OCVAR_SKIP_CROP_KERNELS set -- timing experiment, detection results are NOT valid\n");
+        warned = true;
+    }
     if (only_binarise) stages = 0;
     HIP_TRY(c, hop(1, s, f));
     if (stages > 0) {
