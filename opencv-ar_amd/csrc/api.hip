@@ -251,6 +251,9 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     // than 128 steps to the wave tier, which crosses straight runs 64 pixels at a time (1080p, one frame per call: 3.2 ->
     // 2.5 ms).  Large batches keep the long budget: there the one-lane walks are what fills the machine.
     w.mid_steps = std::getenv("OCVAR_MID_STEPS") ? std::atoi(std::getenv("OCVAR_MID_STEPS")) : (n_frames <= 8 ? 128 : MID_STEPS);
+    // Crop tier 2 in two phases saves half of its steps but chains two launches: throughput for batches (+1..2 %), 0.1 ms of
+    // latency for a one-frame call -- which therefore keeps the single launch (env OCVAR_CROP_PHASES overrides).
+    w.crop_phases = std::getenv("OCVAR_CROP_PHASES") ? (std::atoi(std::getenv("OCVAR_CROP_PHASES")) == 1 ? 1 : 2) : (n_frames <= 8 ? 1 : 2);
     w.mid_blocks = std::getenv("OCVAR_MID_BLOCKS") ? std::atoi(std::getenv("OCVAR_MID_BLOCKS")) : w.max_mid_blocks;
     if (w.mid_blocks < 1 || w.mid_blocks > w.max_mid_blocks) w.mid_blocks = w.max_mid_blocks;
     w.long_blocks = std::getenv("OCVAR_LONG_BLOCKS") ? std::atoi(std::getenv("OCVAR_LONG_BLOCKS")) : w.max_long_blocks;

@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) OCVAR_MID_ATTR void follow_mid_kernel(Workspac
                         const bool beaten = (unsigned)(ws.best_crop[c.roi] >> 32) < (unsigned)c.pos;
                         if (phase == 1) take = idx < n_first || c.pos == earliest;
                         else if (phase == 2) take = c.pos != earliest && !beaten;
-                        else take = !beaten;   // phase 0 on crops (OCVAR_CROP_PHASES=1): one launch, pruning only by what happens to be finished
+                        else take = !beaten;   // phase 0 on crops (Workspace::crop_phases == 1): one launch, pruning only by what happens to be finished
                     }
                     pl = plane_of<CROP>(ws, c.roi);
                     if (take && c.pos > 0 && c.pos < pl.plane) {
@@ -1165,8 +1165,7 @@ void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_mid_kernel<false>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 0);
 }
 void launch_follow_mid_crops(const Workspace& ws, hipStream_t stream) {
-    static const bool one_phase = std::getenv("OCVAR_CROP_PHASES") && std::atoi(std::getenv("OCVAR_CROP_PHASES")) == 1;
-    if (one_phase) {
+    if (ws.crop_phases == 1) {
         hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 0);
         return;
     }

@@ -58,6 +58,7 @@ struct Workspace {
     long long cap_pool_ints, cap_crop_pixels;
     // per batch geometry
     int W, H, sw, sh, ns, n_frames, n_templates;   // ns: row stride of a neighbour-mask plane = sw rounded up to 4
+    int crop_phases;                         // 2: crop tier 2 in two launches (earliest starts first, then the rest behind exact pruning); 1: one launch (few frames: the shorter chain)
     int mid_steps, mid_blocks, long_blocks;  // tuning (env OCVAR_MID_STEPS / OCVAR_MID_BLOCKS / OCVAR_LONG_BLOCKS): tier-2 step budget and grid, tier-3 grid
     int max_mid_blocks, max_long_blocks;     // slabs allocated at create (scaled with max_batch)
     int short_blocks, crop_blocks;           // grids of follower tier 1 and of the crop binarise kernel (scaled with the batch)
