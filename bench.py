@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the AR-marker detection path (BASELINE.json metric) on N MI355X.
 
-A "step" is one pass of the whole hot path (11 kernels: binarise, follower tiers 1-3, order/crops, binarise crops,
-follower tiers 1-3 on the crops, decode, dedupe+pose, and the copy-out of the CvarMarker arrays) over one batch of
+A "step" is one pass of the whole hot path (12 launches: binarise, follower tiers 1-3, order/crops, binarise crops,
+follower tiers 1, 2 (two phases), 3 on the crops, decode, dedupe+pose, and the copy-out of the CvarMarker arrays) over one batch of
 synthetic frames per GPU.
 Workload at every N: BASELINE.json configs[2] -- 1920x1080, 16 planted markers/frame, templates 2x2/3x3/4x4.
 Frames are resident in HBM before the timed region.  For N > 1 (one process per GPU, torchrun) frames are

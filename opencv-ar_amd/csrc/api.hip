@@ -1,9 +1,9 @@
 // api.hip -- the thin C ABI of include/ocvar_hip.h: context, device workspace, launch sequence, result copy-out.
 //
-// One batch = 11 kernel launches on one HIP stream, no host round trip in between (work counts stay in
+// One batch = 12 kernel launches on one HIP stream, no host round trip in between (work counts stay in
 // device memory and the second-pass kernels are launched with fixed grids that read them):
-//   binarise(frames) -> follower tiers 1,2,3 (frames) -> order+crops -> binarise(crops) -> follower tiers 1,2,3 (crops)
-//   -> decode -> finalise
+//   binarise(frames) -> follower tiers 1,2,3 (frames) -> order+crops -> binarise(crops) -> follower tiers 1, 2 (two phases:
+//   follow.hip), 3 (crops) -> decode -> finalise
 // There is deliberately no CPU path here: if the device or the code object is missing, create() fails.
 #include "kernels.h"
 #include <cstdio>
