@@ -150,8 +150,11 @@ def main():
     frame_bytes = W * Hh * 3
     # result blocks for the RCCL gather, double-buffered: launches enqueued during step k write buffer (k+1)%2 while the
     # gather at the end of step k reads buffer k%2 (filled by the launches that were collected during step k)
-    d_res = [torch.zeros(S.block_bytes(B), dtype=torch.uint8, device="cuda") for _ in range(2)]
-    nbytes_m = B * S.MAX_MARKERS * S.MARKER_BYTES
+    # (GATHER_K records per frame travel: a stateless frame yields at most one marker per template -- the `||` dedupe,
+    # opencvar.cpp:784-785 --, the gathered counts are the frames' full counts and are checked against GATHER_K in the warm-up)
+    GATHER_K = 8
+    d_res = [torch.zeros(S.block_bytes(B, GATHER_K), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    nbytes_m = B * GATHER_K * S.MARKER_BYTES
 
     # K steps as a software pipeline.  Every context runs its sub-batches back to back on its own stream; the contexts are
     # staggered by 1/NS of a sub-batch (context i's first launch covers (i+1)/NS of its sub-batch, its last launch the
@@ -168,8 +171,8 @@ def main():
         o = int(offs[i]) + skip
         dets[i].enqueue_device(d_frames.data_ptr() + o * frame_bytes, W, Hh, n, stream=streams[i].cuda_stream)
         if world > 1:
-            dets[i].results_to_device(d_res[buf].data_ptr() + o * S.MAX_MARKERS * S.MARKER_BYTES,
-                                      d_res[buf].data_ptr() + nbytes_m + 4 * o, streams[i].cuda_stream)
+            dets[i].results_to_device(d_res[buf].data_ptr() + o * GATHER_K * S.MARKER_BYTES,
+                                      d_res[buf].data_ptr() + nbytes_m + 4 * o, streams[i].cuda_stream, per_frame=GATHER_K)
         last[i] = n
 
     def collect(i, timed):
@@ -196,8 +199,9 @@ def main():
             if world > 1:   # one gather of the ranks' result blocks per step (the launches that filled this buffer are complete)
                 blocks = S.gather_blocks(d_res[k % 2], rank, world, dist)
                 torch.cuda.current_stream().synchronize()
-                if rank == 0 and not timed:
-                    S.unpack(blocks, B, oa.MARKER_DTYPE)  # warm-up only: checks the gathered blocks decode
+                if rank == 0 and not timed:   # warm-up only: the gathered blocks decode and no frame has more markers than a block keeps
+                    got = S.unpack(blocks, B, oa.MARKER_DTYPE, GATHER_K)
+                    assert max(c for c, _ in got.values()) <= GATHER_K, "a frame has more markers than the gathered block keeps"
         for i in list(last):
             parts[i] = collect(i, timed)
             last.pop(i)
@@ -270,7 +274,7 @@ def main():
             "config": {"workload": f"configs[{args.config - 1}]: {W}x{Hh}, {cfg.grid_x * cfg.grid_y} markers/frame, templates "
                                    f"{'2x2' if names else '2x2/3x3/4x4 x 4 rotations'}, batch {B} frames/GPU/step "
                                    f"({uniq} distinct) in {NS} stream(s), stateless", "frames_per_step_per_gpu": B, "streams": NS,
-                       "parallelism": f"frame-sharded x{world}" + ((", RCCL gather of CvarMarker arrays" if backend == "nccl" else f", {backend} rehearsal of the gather (ranks share devices)") if world > 1 else "")},
+                       "parallelism": f"frame-sharded x{world}" + ((f", RCCL gather of CvarMarker arrays ({GATHER_K} records per frame + counts)" if backend == "nccl" else f", {backend} rehearsal of the gather (ranks share devices)") if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "launch_ms": round(float(stage_ms[dom[1]]), 4), "alg_bytes_per_launch": round(dom[2])},

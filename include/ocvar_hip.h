@@ -94,6 +94,10 @@ int ocvar_hip_collect(OcvarHip* ctx, OcvarMarker* markers, int* counts, int max_
  * buffers, d_markers [n_frames][OCVAR_MAX_MARKERS] and d_counts [n_frames] -- for callers that gather results
  * across GPUs (RCCL) before any host copy.  Does not wait; ocvar_hip_collect must still be called. */
 int ocvar_hip_results_to_device(OcvarHip* ctx, OcvarMarker* d_markers, int* d_counts, void* stream);
+/* Same with a narrower block: d_markers [n_frames][max_per_frame] (1 <= max_per_frame <= OCVAR_MAX_MARKERS) holds the first
+ * max_per_frame records of every frame; d_counts still carries the frames' full counts, so a frame with more markers than
+ * the block keeps is visible to the receiver.  A gather of 8 records per frame moves 1/8 of the bytes over xGMI. */
+int ocvar_hip_results_to_device_ex(OcvarHip* ctx, OcvarMarker* d_markers, int* d_counts, int max_per_frame, void* stream);
 
 /* Same, frames in host memory (copied over PCIe first; greyed frames are copied back when requested). */
 int ocvar_hip_detect_host(OcvarHip* ctx, uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,

@@ -24,7 +24,7 @@ HIP_SYMBOLS = [
     "ocvar_hip_create", "ocvar_hip_create_ex", "ocvar_hip_capacity_flags", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
     "ocvar_hip_detect_device", "ocvar_hip_enqueue", "ocvar_hip_collect", "ocvar_hip_detect_host", "ocvar_hip_find_squares",
     "ocvar_hip_debug_gray", "ocvar_hip_debug_binary", "ocvar_hip_debug_frame_quads", "ocvar_hip_debug_candidates",
-    "ocvar_hip_stage_ms", "ocvar_hip_counters", "ocvar_hip_results_to_device", "ocvar_hip_debug_calibrate",
+    "ocvar_hip_stage_ms", "ocvar_hip_counters", "ocvar_hip_results_to_device", "ocvar_hip_results_to_device_ex", "ocvar_hip_debug_calibrate",
 ]
 STAGE_NAMES = ["binarise_frames", "follow1_frames", "follow2_frames", "follow3_frames", "order_crops", "binarise_crops",
                "follow1_crops", "follow2_crops", "follow3_crops", "decode", "dedupe_pose", "batch_total"]
@@ -95,6 +95,7 @@ def hip_lib():
         lib.ocvar_hip_stage_ms.argtypes = [vp, vp, i]
         lib.ocvar_hip_counters.argtypes = [vp, vp, i]
         lib.ocvar_hip_results_to_device.argtypes = [vp, vp, vp, vp]
+        lib.ocvar_hip_results_to_device_ex.argtypes = [vp, vp, vp, i, vp]
         lib.ocvar_hip_debug_calibrate.argtypes = [vp, sz]
         _hip = lib
     return _hip
@@ -213,10 +214,10 @@ class Detector:
         self._check(self._lib.ocvar_hip_collect(self._ctx, _ptr(markers), _ptr(counts), max_per_frame), "collect")
         return markers, counts
 
-    def results_to_device(self, d_markers_ptr, d_counts_ptr, stream=None):
-        """Copies the enqueued batch's [n][MAX_MARKERS] marker records and [n] counts into caller-owned device
-        buffers (stream-ordered), e.g. torch tensors handed to an RCCL gather."""
-        self._check(self._lib.ocvar_hip_results_to_device(self._ctx, d_markers_ptr, d_counts_ptr, stream), "results_to_device")
+    def results_to_device(self, d_markers_ptr, d_counts_ptr, stream=None, per_frame=MAX_MARKERS):
+        """Copies the enqueued batch's [n][per_frame] marker records (the first per_frame of every frame) and [n] full counts
+        into caller-owned device buffers (stream-ordered), e.g. torch tensors handed to an RCCL gather."""
+        self._check(self._lib.ocvar_hip_results_to_device_ex(self._ctx, d_markers_ptr, d_counts_ptr, per_frame, stream), "results_to_device")
 
     def detect_device(self, d_ptr, width, height, n_frames, **kw):
         max_per_frame = kw.pop("max_per_frame", MAX_MARKERS)

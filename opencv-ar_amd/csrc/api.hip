@@ -391,14 +391,22 @@ extern "C" int ocvar_hip_enqueue(OcvarHip* c, uint8_t* d_bgr, int width, int hei
 }
 
 extern "C" int ocvar_hip_results_to_device(OcvarHip* c, OcvarMarker* d_markers, int* d_counts, void* stream) {
-    if (!c || !d_markers || !d_counts || !c->pending) return OCVAR_E_ARG;
+    return ocvar_hip_results_to_device_ex(c, d_markers, d_counts, MAXM, stream);
+}
+
+extern "C" int ocvar_hip_results_to_device_ex(OcvarHip* c, OcvarMarker* d_markers, int* d_counts, int max_per_frame, void* stream) {
+    if (!c || !d_markers || !d_counts || !c->pending || max_per_frame < 1 || max_per_frame > MAXM) return OCVAR_E_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->last_stream;
     if (s != c->last_stream) {  // order behind the batch
         HIP_TRY(c, hipStreamWaitEvent(s, c->ev[12], 0));
     }
     const int n = c->ws.n_frames;
-    HIP_TRY(c, hipMemcpyAsync(d_markers, c->ws.markers, (size_t)n * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToDevice, s));
+    if (max_per_frame == MAXM)
+        HIP_TRY(c, hipMemcpyAsync(d_markers, c->ws.markers, (size_t)n * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToDevice, s));
+    else   // the first max_per_frame records of every frame: a strided copy
+        HIP_TRY(c, hipMemcpy2DAsync(d_markers, (size_t)max_per_frame * sizeof(MarkerRec), c->ws.markers, (size_t)MAXM * sizeof(MarkerRec),
+                                    (size_t)max_per_frame * sizeof(MarkerRec), (size_t)n, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_counts, c->ws.n_markers, n * sizeof(int), hipMemcpyDeviceToDevice, s));
     return OCVAR_OK;
 }

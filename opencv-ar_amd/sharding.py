@@ -2,7 +2,9 @@
 
 Frames are independent work units: rank r owns global frames r, r+N, r+2N, ...; the only exchange is
 one gather of the fixed-size result block per batch to rank 0 (backend "nccl" = RCCL over xGMI on the GPUs,
-"gloo" in the CPU tests).  Result block per rank: B x MAX_MARKERS CvarMarker records (184 B) then B int32 counts."""
+"gloo" in the CPU tests).  Result block per rank: B x per_frame CvarMarker records (184 B) then B int32 counts; per_frame
+is MAX_MARKERS unless the caller knows a tighter bound for its frames (the counts are the full counts either way, so a frame
+with more markers than its block keeps is seen on rank 0)."""
 import numpy as np
 import torch
 
@@ -14,8 +16,8 @@ def frame_of(rank, world, local_index):
     return rank + world * local_index
 
 
-def block_bytes(batch):
-    return batch * MAX_MARKERS * MARKER_BYTES + 4 * batch
+def block_bytes(batch, per_frame=MAX_MARKERS):
+    return batch * per_frame * MARKER_BYTES + 4 * batch
 
 
 def gather_blocks(local_block, rank, world, dist=None):
@@ -31,14 +33,14 @@ def gather_blocks(local_block, rank, world, dist=None):
     return out
 
 
-def unpack(blocks, batch, marker_dtype):
-    """blocks (rank order) -> dict global_frame -> (count, markers[:min(count, MAX_MARKERS)]) on rank 0"""
+def unpack(blocks, batch, marker_dtype, per_frame=MAX_MARKERS):
+    """blocks (rank order) -> dict global_frame -> (count, markers[:min(count, per_frame)]) on rank 0"""
     world = len(blocks)
     res = {}
     for r, blk in enumerate(blocks):
         raw = blk.cpu().numpy()
-        markers = raw[:batch * MAX_MARKERS * MARKER_BYTES].view(marker_dtype).reshape(batch, MAX_MARKERS)
-        counts = raw[batch * MAX_MARKERS * MARKER_BYTES:].view(np.int32)
+        markers = raw[:batch * per_frame * MARKER_BYTES].view(marker_dtype).reshape(batch, per_frame)
+        counts = raw[batch * per_frame * MARKER_BYTES:].view(np.int32)
         for i in range(batch):
-            res[frame_of(r, world, i)] = (int(counts[i]), markers[i, :min(int(counts[i]), MAX_MARKERS)].copy())
+            res[frame_of(r, world, i)] = (int(counts[i]), markers[i, :min(int(counts[i]), per_frame)].copy())
     return res

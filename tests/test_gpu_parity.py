@@ -298,6 +298,18 @@ def test_results_to_device_block_equals_collect(oa):
         c, m = res[f]
         assert c == counts[f] and c >= 1
         assert m.tobytes() == markers[f, :c].tobytes()
+    # the narrow block (ocvar_hip_results_to_device_ex, what bench.py gathers): the first K records of every frame, full counts
+    for K in (1, 3):
+        narrow = torch.zeros(S.block_bytes(n, K), dtype=torch.uint8, device="cuda")
+        det.enqueue_device(d.data_ptr(), cfg.width, cfg.height, n)
+        det.results_to_device(narrow.data_ptr(), narrow.data_ptr() + n * K * S.MARKER_BYTES, per_frame=K)
+        det.collect()
+        torch.cuda.synchronize()
+        res = S.unpack([narrow], n, oa.MARKER_DTYPE, K)
+        for f in range(n):
+            c, m = res[f]
+            assert c == counts[f] and len(m) == min(c, K)
+            assert m.tobytes() == markers[f, :min(c, K)].tobytes()
 
 
 def test_round_trip_properties_full_size(oa):
