@@ -312,6 +312,34 @@ def test_results_to_device_block_equals_collect(oa):
             assert m.tobytes() == markers[f, :min(c, K)].tobytes()
 
 
+def test_crop_pass_one_and_two_phases_give_the_same_results(oa):
+    """The crop pass walks a crop's borders in one launch (batches of <= 8 frames) or in two with exact pruning behind the
+    crop's best quad (follow.hip::follow_mid_kernel): both forms, forced on the same textured frames, equal the oracle --
+    and with it each other -- candidate for candidate."""
+    import os
+    import torch
+    cfg = H.synth_config(3, width=800, height=600, grid_x=3, grid_y=2, textured=1, corner_jitter_pct=6, occlude_pct=20)
+    n = 10
+    det, tpls, cam = make_detector(oa, cfg, None, n)
+    frames = np.stack([H.synth_frame(cfg, 100 + f)[0] for f in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    old = os.environ.get("OCVAR_CROP_PHASES")
+    try:
+        got = {}
+        for phases in ("1", "2"):
+            os.environ["OCVAR_CROP_PHASES"] = phases
+            markers, counts = det.detect_device(d.data_ptr(), cfg.width, cfg.height, n)
+            for f in range(n):
+                check_frame(det, f, frames[f], tpls, cam, markers, counts)
+            got[phases] = (markers.tobytes(), counts.tobytes())
+        assert got["1"] == got["2"]
+    finally:
+        if old is None:
+            os.environ.pop("OCVAR_CROP_PHASES", None)
+        else:
+            os.environ["OCVAR_CROP_PHASES"] = old
+
+
 def test_round_trip_properties_full_size(oa):
     """Size-independent properties at the headline size: determinism across batch positions, and every decoded
     4x4 marker's quad lies on a planted marker (corner within 12 px of the truth: the decoded quad is the inner border)."""

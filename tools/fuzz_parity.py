@@ -44,6 +44,10 @@ for s in range(n_scenes):
         frames.append(np.clip(img, 0, 255).astype(np.uint8))
     frames = np.ascontiguousarray(np.stack(frames))
     det, tpls, cam = T.make_detector(oa, cfg, names, nb)
+    # the crop pass's two forms (follow.hip::follow_mid_kernel): the batch-size default, one launch, two launches with pruning
+    os.environ.pop("OCVAR_CROP_PHASES", None)
+    if s % 3:
+        os.environ["OCVAR_CROP_PHASES"] = str(s % 3)
     if s % 4 == 3:     # stateful: every lane is a video stream, the scene drifts a few pixels per step (opencvar.cpp:635-668)
         from opencv_ar_amd.tracking import StreamTracker
         tracker = StreamTracker(det, nb)
