@@ -9,7 +9,6 @@
 // rectangle set-up of the candidate loop (676-693).
 #include "kernels.h"
 #include "trace_core.h"
-#include <cstdlib>
 
 namespace ocvar {
 
@@ -627,10 +626,7 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
 // most lanes would sit idle behind the longest border (a crop holds a ~900-step border next to 100-step ones).  Here a
 // lane whose walk has ended is retired every MID_BLOCK steps -- routed on, or approximated by the whole wave from its
 // slab -- and takes the next start from the list, so the lanes stay busy until the list is empty.
-#ifndef OCVAR_MID_BLOCK
-#define OCVAR_MID_BLOCK 32
-#endif
-constexpr int MID_BLOCK = OCVAR_MID_BLOCK;
+constexpr int MID_BLOCK = 32;
 // A walk's corner points are not stored to its slab step by step -- 64 lanes x one dword in 64 different cache lines per
 // step made the stores, not the dependent mask loads, the bulk of this kernel's time (1.7 of 2.8 ms per 2048 frames) --
 // but parked in LDS (row of POINT_ROW dwords per lane: up to MID_BLOCK points + the dummy slot of steps without a point;
@@ -640,9 +636,6 @@ constexpr int POINT_ROW = MID_BLOCK + 1;
 constexpr int FLUSH_W = MID_BLOCK <= 16 ? 16 : 32;   // lanes that carry one walk's parked points in a flush (>= MID_BLOCK)
 static_assert(FLUSH_W >= MID_BLOCK && 64 % FLUSH_W == 0, "a group of lanes covers a whole row of parked points");
 
-#ifndef OCVAR_MID_ATTR
-#define OCVAR_MID_ATTR
-#endif
 // Crops, exact pruning: of a crop's quads only the one that starts earliest is used (cvarGetSquare keeps the sequence's last
 // quad, opencvar.cpp:401-430), so a border that starts after a quad the crop already has can never matter -- it is not
 // walked, and a walked one is not approximated.  To have that quad early, a crop's borders are walked in two launches:
@@ -651,7 +644,7 @@ static_assert(FLUSH_W >= MID_BLOCK && 64 % FLUSH_W == 0, "a group of lanes cover
 // what is left and skips every start behind its crop's best quad -- the outline's other side, the code cells, and the
 // staircase starts inside them: about half of a crop's steps.  Frames keep all their quads: one launch, phase 0.
 template <bool CROP>
-__global__ __launch_bounds__(256) OCVAR_MID_ATTR void follow_mid_kernel(Workspace ws, int phase) {
+__global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws, int phase) {
     __shared__ WaveScratch scratch[4];
     __shared__ unsigned parked[4][64 * POINT_ROW];
     const StartCand* cands = CROP ? ws.mid_crop : ws.mid_frame;
