@@ -21,10 +21,7 @@ constexpr int SHORT_STEPS = 96;            // step budget of follower tier 1 (ev
 constexpr int MID_STEPS = 1536;            // step budget of tier 2 (borders that outlived tier 1, one lane each); the rest: tier 3, one wave each
 constexpr int SLAB_PTS = 1024;             // points (packed x | y << 16) a tier-2 lane can keep in its private slab (no second follow needed below that)
 constexpr int SLAB_STRIDE = SLAB_PTS + 4;  // dwords per tier-2 lane slab: the points + the scratch slot of flat_step
-#ifndef OCVAR_MID_BLOCKS_MAX
-#define OCVAR_MID_BLOCKS_MAX 1024
-#endif
-constexpr int MID_BLOCKS_MAX = OCVAR_MID_BLOCKS_MAX;       // tier-2 grid limit (x256 threads, one slab each)
+constexpr int MID_BLOCKS_MAX = 1024;       // tier-2 grid limit (x256 threads, one slab each)
 constexpr int SLAB3_PTS = 8192;            // points a tier-3 wave can keep in its slab
 constexpr int SLAB3_STRIDE = SLAB3_PTS + 64;   // dwords per tier-3 wave slab
 constexpr int LONG_BLOCKS_MAX = 1024;      // tier-3 grid limit (x4 waves, one slab each)
