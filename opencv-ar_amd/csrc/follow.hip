@@ -725,8 +725,11 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws, int phase
             PROF_ADD(4, 1);
             PROF_ADD(5, __popcll(__ballot(running)));
             if (running)
-                flat_step_t<false>(w, pl.nbr, pl.ns, pl.plane, c.pos, budget, [&](bool emit, int x, int y) {
-                    my_row[(emit && w.npts < SLAB_PTS) ? w.npts - flushed : MID_BLOCK] = (unsigned)x | ((unsigned)y << 16);
+                flat_step_t<false>(w, pl.nbr, pl.ns, pl.plane, c.pos, budget, [&](bool, int x, int y) {
+                    // every step writes its pixel at the running count; only a corner point advances the count, so a step
+                    // without one is overwritten by the next (beyond the slab's capacity: the row's spare slot)
+                    const int slot = w.npts - flushed;
+                    my_row[slot < MID_BLOCK ? slot : MID_BLOCK] = (unsigned)x | ((unsigned)y << 16);
                 });
         }
         // the step budget is checked here, once per block, instead of in every step (a walk may overshoot it by up to

@@ -338,25 +338,30 @@ OCVAR_HD void flat_step_t(FlatWalk& w, const uint8_t* nbr, int ns, int plane, in
     // (bitwise & and | on purpose: with && and || the compiler turns these predicates into nested divergent branches --
     // EXEC save/restore and a scalar branch per condition and step)
     const bool budget = BUDGET & (w.step >= max_steps);
-    const bool nf = !budget & ((((passed & 0x10u) != 0) & (w.idx < cpos)) | (((passed & 1u) != 0) & (w.idx + 1 < cpos)));
+    // the scan positions of this border at this pixel -- west side passed: idx, east side passed: idx + 1 -- against cpos, as
+    // sign bits lined up with `passed` (bit 4 = W, bit 0 = E)
+    const unsigned early = (((unsigned)(w.idx - cpos) >> 31) << 4) | ((unsigned)(w.idx + 1 - cpos) >> 31);
+    const bool nf = !budget & ((passed & early) != 0u);
     const int dx = step_dx(e), dy = step_dy(e);
     const int nidx = w.idx + mul_small(dy, ns) + dx;
     const bool closes = !budget & !nf & (nidx == w.i0) & (w.idx == w.i1);
-    const bool oob = !budget & !nf & !closes & ((unsigned)nidx >= (unsigned)plane);
-    const bool go = !(budget | nf | closes | oob);
-    const bool emit = (e != w.prev_s) & (go | closes);   // CHAIN_APPROX_SIMPLE: a point wherever the direction changes
-    const int lx = go ? w.x + dx : w.x, ly = go ? w.y + dy : w.y;
-    const unsigned m4 = nbr[nbr_addr(lx, ly, ns)];
+    const bool oob = (unsigned)nidx >= (unsigned)plane;   // cannot happen on a consistent plane; never read outside it
+    // A walk that ends in this step is not stepped again (the callers loop while status < 0), so nothing below is guarded by
+    // "the walk goes on": the position, the directions and the point count of an ended walk may be off by this one step --
+    // except for a border that closes, whose last corner point is exactly this pixel (emit as for any other step).
+    const bool emit = !budget & (e != w.prev_s);          // CHAIN_APPROX_SIMPLE: a point wherever the direction changes
+    const int lx = w.x + dx, ly = w.y + dy;
+    const unsigned m4 = nbr[oob ? 0u : nbr_addr(lx, ly, ns)];
     store(emit, w.x, w.y);
     w.npts += emit ? 1 : 0;
-    w.status = budget ? (int)TRACE_OVERRUN : nf ? (int)TRACE_NOT_FIRST : closes ? (int)TRACE_OK : (oob || m4 == 0) ? (int)TRACE_OVERRUN : -1;
-    w.step += go ? 1 : 0;
+    w.status = budget ? (int)TRACE_OVERRUN : nf ? (int)TRACE_NOT_FIRST : closes ? (int)TRACE_OK : (oob | (m4 == 0u)) ? (int)TRACE_OVERRUN : -1;
+    w.step += w.status < 0 ? 1 : 0;
     w.x = lx;
     w.y = ly;
-    w.idx = go ? nidx : w.idx;
-    w.prev_s = go ? e : w.prev_s;
+    w.idx = nidx;
+    w.prev_s = e;
     w.m = m4;
-    w.s = go ? (e ^ 4) : w.s;
+    w.s = e ^ 4;
 }
 
 // points as x,y int pairs in out (max_pts + 1 pairs: a step without a point stores into the scratch slot behind the last)
