@@ -70,6 +70,18 @@ const char* ocvar_hip_last_error(const OcvarHip* ctx);
  * frame, 8 trace overrun, 16 crops, 32 crop tiles, 64 work-queue runaway, 128 markers per frame.  0 after a good call. */
 int ocvar_hip_capacity_flags(const OcvarHip* ctx);
 
+/* Several contexts in flight on one GPU (each with its own stream) overlap the latency-bound border followers of one batch
+ * with the streaming binarise kernels of another -- but left alone they drift: a quarter of the time none of them is in a
+ * binarise kernel and a sixth of the time three are (rocprofv3 trace of bench.py).  A gate shared by the
+ * contexts lets at most `width` binarise kernels run at once (stream-ordered: the n-th binarise launch waits for the
+ * (n - width)-th to finish; nothing blocks on the host), so that more contexts can be kept in flight to always have one
+ * ready.  No counterpart in the reference (it processes one frame per call). */
+typedef struct OcvarGate OcvarGate;
+int ocvar_hip_gate_create(OcvarGate** gate, int device, int width);
+void ocvar_hip_gate_destroy(OcvarGate* gate);
+/* gate may be NULL (no gate: the default).  The gate must outlive the batches enqueued under it. */
+int ocvar_hip_set_gate(OcvarHip* ctx, OcvarGate* gate);
+
 int ocvar_hip_set_templates(OcvarHip* ctx, const OcvarTemplate* templates, int n);
 int ocvar_hip_set_camera(OcvarHip* ctx, const OcvarCamera* camera);
 

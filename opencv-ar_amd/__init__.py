@@ -21,7 +21,7 @@ MAX_TEMPLATES, MAX_QUADS, MAX_MARKERS = 16, 256, 64
 
 # every symbol include/ocvar_hip.h declares
 HIP_SYMBOLS = [
-    "ocvar_hip_create", "ocvar_hip_create_ex", "ocvar_hip_capacity_flags", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
+    "ocvar_hip_create", "ocvar_hip_create_ex", "ocvar_hip_capacity_flags", "ocvar_hip_gate_create", "ocvar_hip_gate_destroy", "ocvar_hip_set_gate", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
     "ocvar_hip_detect_device", "ocvar_hip_enqueue", "ocvar_hip_collect", "ocvar_hip_detect_host", "ocvar_hip_find_squares",
     "ocvar_hip_debug_gray", "ocvar_hip_debug_binary", "ocvar_hip_debug_frame_quads", "ocvar_hip_debug_candidates",
     "ocvar_hip_stage_ms", "ocvar_hip_counters", "ocvar_hip_results_to_device", "ocvar_hip_results_to_device_ex", "ocvar_hip_debug_calibrate",
@@ -78,6 +78,10 @@ def hip_lib():
         vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
         lib.ocvar_hip_create.argtypes = [C.POINTER(vp), i, i, i, i]
         lib.ocvar_hip_destroy.argtypes = [vp]
+        lib.ocvar_hip_gate_create.argtypes = [C.POINTER(vp), i, i]
+        lib.ocvar_hip_gate_destroy.argtypes = [vp]
+        lib.ocvar_hip_gate_destroy.restype = None
+        lib.ocvar_hip_set_gate.argtypes = [vp, vp]
         lib.ocvar_hip_destroy.restype = None
         lib.ocvar_hip_last_error.argtypes = [vp]
         lib.ocvar_hip_last_error.restype = C.c_char_p
@@ -144,6 +148,22 @@ def default_camera(width, height, filename=None):
 
 def _ptr(a):
     return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class Gate:
+    """At most `width` binarise kernels of the detectors that share the gate run at once (include/ocvar_hip.h)."""
+
+    def __init__(self, width=2, device=0):
+        self._lib = hip_lib()
+        self._g = C.c_void_p()
+        rc = self._lib.ocvar_hip_gate_create(C.byref(self._g), device, width)
+        if rc != 0:
+            raise OcvarError(f"ocvar_hip_gate_create failed ({rc})")
+
+    def __del__(self):
+        if getattr(self, "_g", None):
+            self._lib.ocvar_hip_gate_destroy(self._g)
+            self._g = None
 
 
 class Detector:
@@ -213,6 +233,11 @@ class Detector:
         counts = np.zeros(n, np.int32)
         self._check(self._lib.ocvar_hip_collect(self._ctx, _ptr(markers), _ptr(counts), max_per_frame), "collect")
         return markers, counts
+
+    def set_gate(self, gate):
+        """share a Gate with other detectors on the same GPU (None removes it); the detector keeps the gate alive"""
+        self._check(self._lib.ocvar_hip_set_gate(self._ctx, gate._g if gate is not None else None), "set_gate")
+        self._gate = gate
 
     def results_to_device(self, d_markers_ptr, d_counts_ptr, stream=None, per_frame=MAX_MARKERS):
         """Copies the enqueued batch's [n][per_frame] marker records (the first per_frame of every frame) and [n] full counts

@@ -19,8 +19,18 @@ static_assert(sizeof(TemplateRec) == sizeof(OcvarTemplate) && sizeof(TemplateRec
 static_assert(sizeof(CameraRec) == sizeof(OcvarCamera) && sizeof(CameraRec) == 248, "CvarCamera layout");
 static_assert(sizeof(MarkerRec) == sizeof(OcvarMarker) && sizeof(MarkerRec) == 184, "CvarMarker layout");
 
+// At most `width` binarise kernels of the contexts that share the gate run at once: launch n waits (on its stream) for the
+// event recorded behind launch n - width.  Host side only keeps the ring of events.
+struct OcvarGate {
+    int device = 0;
+    int width = 2;
+    unsigned long long issued = 0;
+    std::vector<hipEvent_t> ring;   // far more slots than launches can be in flight (contexts x 2)
+};
+
 struct OcvarHip {
     int device = 0;
+    OcvarGate* gate = nullptr;
     Workspace ws{};
     hipStream_t stream = nullptr;
     hipStream_t hp_stream = nullptr;   // high-priority stream of the latency-bound kernels (env OCVAR_SPLIT_STREAMS=1; default off)
@@ -187,6 +197,52 @@ extern "C" void ocvar_hip_destroy(OcvarHip* c) {
     delete c;
 }
 
+extern "C" int ocvar_hip_gate_create(OcvarGate** out, int device, int width) {
+    if (!out || width < 1 || width > 64) return OCVAR_E_ARG;
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return OCVAR_E_NO_DEVICE;
+    OcvarGate* g = new (std::nothrow) OcvarGate();
+    if (!g) return OCVAR_E_HIP;
+    g->device = device;
+    g->width = width;
+    g->ring.resize(256);
+    for (auto& e : g->ring)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            for (auto& d : g->ring)
+                if (d) (void)hipEventDestroy(d);
+            delete g;
+            return OCVAR_E_HIP;
+        }
+    *out = g;
+    return OCVAR_OK;
+}
+
+extern "C" void ocvar_hip_gate_destroy(OcvarGate* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    for (auto& e : g->ring)
+        if (e) (void)hipEventDestroy(e);
+    delete g;
+}
+
+extern "C" int ocvar_hip_set_gate(OcvarHip* c, OcvarGate* g) {
+    if (!c || (g && g->device != c->device)) return OCVAR_E_ARG;
+    c->gate = g;
+    return OCVAR_OK;
+}
+
+// before / after a gated launch on stream s
+static hipError_t gate_enter(OcvarGate* g, hipStream_t s) {
+    if (!g || g->issued < (unsigned long long)g->width) return hipSuccess;
+    return hipStreamWaitEvent(s, g->ring[(g->issued - g->width) % g->ring.size()], 0);
+}
+static hipError_t gate_leave(OcvarGate* g, hipStream_t s) {
+    if (!g) return hipSuccess;
+    const hipError_t e = hipEventRecord(g->ring[g->issued % g->ring.size()], s);
+    g->issued++;
+    return e;
+}
+
 extern "C" const char* ocvar_hip_last_error(const OcvarHip* c) { return c ? c->err.c_str() : "null context"; }
 extern "C" int ocvar_hip_capacity_flags(const OcvarHip* c) { return c ? c->capacity_flags : 0; }
 
@@ -300,8 +356,10 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
         if (e == hipSuccess && from != to) e = hipStreamWaitEvent(to, c->ev[k], 0);
         return e;
     };
+    HIP_TRY(c, gate_enter(c->gate, s));   // (before the first timing event: a wait at the gate is not binarise time)
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     launch_binarise_frames(w, d_bgr, row_stride, frame_stride, grey_in_place, s);
+    HIP_TRY(c, gate_leave(c->gate, s));
     TRACE_LAUNCH("binarise_frames", s);
     // Timing experiments (results are then incomplete or wrong; never set in production):
     //   OCVAR_ONLY_BINARISE=1        stop after the first kernel (tools/binarise_only.py)
@@ -331,8 +389,10 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
         for (int k = 2; k < 5; k++) HIP_TRY(c, hipEventRecord(c->ev[k], f));
     }
     if (stages > 2) {
+        HIP_TRY(c, gate_enter(c->gate, s));   // (a wait here is booked under the order_crops interval)
         HIP_TRY(c, hop(5, f, s));
         if (!(skip_crop & 1)) launch_binarise_crops(w, s);
+        HIP_TRY(c, gate_leave(c->gate, s));
         TRACE_LAUNCH("binarise_crops", s);
         HIP_TRY(c, hop(6, s, f));
         if (!(skip_crop & 2)) launch_follow_crops(w, f);

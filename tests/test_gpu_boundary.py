@@ -262,3 +262,42 @@ def test_small_frames_in_heap_blocks_never_reach_the_device_directly():
                     assert markers[f, k]["markerId"] == r.markerId and markers[f, k]["templateId"] == r.templateId
                 prev[f] = ref_m
         det.close()
+
+
+@pytest.mark.gpu
+def test_contexts_sharing_a_gate_give_the_same_results():
+    """Two contexts with batches in flight on their own streams, at most one binarise kernel at a time between them
+    (ocvar_hip_gate_create / ocvar_hip_set_gate): same markers as the same batches without the gate, which the parity tests
+    check against the oracle."""
+    import torch
+    import opencv_ar_amd as oa
+    cfg = H.synth_config(2)
+    names = ["2x2-01"]
+    n = 12
+    tpls = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, x + ".png") for x in names])
+    cam = oa.default_camera(cfg.width, cfg.height)
+    frames = [np.stack([H.synth_frame(cfg, 40 * k + f, names)[0] for f in range(n)]) for k in range(2)]
+    d = [torch.from_numpy(f).cuda() for f in frames]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+
+    def run(gate):
+        dets = []
+        for k in range(2):
+            det = oa.Detector(cfg.width, cfg.height, max_batch=n)
+            det.set_templates(tpls)
+            det.set_camera(cam)
+            if gate is not None:
+                det.set_gate(gate)
+            dets.append(det)
+        out = []
+        for rep in range(3):   # several batches per context: the order of the gate's events is exercised
+            for k in range(2):
+                dets[k].enqueue_device(d[k].data_ptr(), cfg.width, cfg.height, n, stream=streams[k].cuda_stream)
+            out = [dets[k].collect(8) for k in range(2)]
+        return [(m.tobytes(), c.tobytes()) for m, c in out]
+
+    plain = run(None)
+    gated = run(oa.Gate(1))
+    assert plain == gated
+    assert all(np.frombuffer(c, np.int32).min() >= 1 for _, c in plain)
