@@ -111,7 +111,10 @@ def main():
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     dist = None
-    if world > 1:
+    # OCVAR_BENCH_FORCE_DIST=1 (under torchrun with one rank): initialise RCCL and run the per-step gather with world 1 -- what
+    # the presence of the communicator and its streams costs the four contexts can then be measured on a one-GPU box
+    force_dist = bool(os.environ.get("OCVAR_BENCH_FORCE_DIST"))
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
@@ -172,11 +175,21 @@ def main():
     frames_done = [0]
     last = {}
 
+    # The gather runs on its own high-priority stream and is never waited for on the host inside a step: a launch that writes a
+    # result buffer again waits (stream-ordered) for the gather that last read it.  (Waiting on the host after every gather
+    # cost 5 %: the collective sits in a hardware queue behind a context's kernels, and meanwhile nothing is collected or
+    # re-enqueued.)
+    gathering = world > 1 or force_dist
+    gather_stream = torch.cuda.Stream(priority=-1) if gathering else None
+    gather_done = [None, None]
+
     def enqueue(i, n, buf, skip=0):
         """context i detects frames [offs[i] + skip, offs[i] + skip + n) of the batch"""
         o = int(offs[i]) + skip
+        if gather_done[buf] is not None:
+            streams[i].wait_event(gather_done[buf])
         dets[i].enqueue_device(d_frames.data_ptr() + o * frame_bytes, W, Hh, n, stream=streams[i].cuda_stream)
-        if world > 1:
+        if gathering:
             dets[i].results_to_device(d_res[buf].data_ptr() + o * GATHER_K * S.MARKER_BYTES,
                                       d_res[buf].data_ptr() + nbytes_m + 4 * o, streams[i].cuda_stream, per_frame=GATHER_K)
         last[i] = n
@@ -202,15 +215,20 @@ def main():
                     enqueue(i, n, (k + 1) % 2, skip=0 if k < K - 1 else first[i])
                 else:
                     last.pop(i)
-            if world > 1:   # one gather of the ranks' result blocks per step (the launches that filled this buffer are complete)
-                blocks = S.gather_blocks(d_res[k % 2], rank, world, dist)
-                torch.cuda.current_stream().synchronize()
+            if gathering:   # one gather of the ranks' result blocks per step (the launches that filled this buffer are complete)
+                with torch.cuda.stream(gather_stream):
+                    blocks = S.gather_blocks(d_res[k % 2], rank, world, dist)
+                    gather_done[k % 2] = torch.cuda.Event()
+                    gather_done[k % 2].record(gather_stream)
                 if rank == 0 and not timed:   # warm-up only: the gathered blocks decode and no frame has more markers than a block keeps
+                    gather_stream.synchronize()
                     got = S.unpack(blocks, B, oa.MARKER_DTYPE, GATHER_K)
                     assert max(c for c, _ in got.values()) <= GATHER_K, "a frame has more markers than the gathered block keeps"
         for i in list(last):
             parts[i] = collect(i, timed)
             last.pop(i)
+        if gathering:
+            gather_stream.synchronize()   # every gather of this run has arrived
         return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
 
     if not args.no_check:
