@@ -319,10 +319,10 @@ def main():
                                            "note": "same kernel, launches not overlapped by other streams (outside the timed region)"},
             "markers_per_frame": round(n_out, 3),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # (the CPU leg and the per-call latency leg: rank 0 of the one-GPU run only)
             tpls = (H.Template * len(tpl_list))(*[H.Template.from_buffer_copy(bytes(t)) for t in tpl_list])
             out["cpu_baseline"] = cpu_baseline(base[:min(uniq, 256)], tpls, H.Camera.from_buffer_copy(bytes(camera)))
-        if not args.no_latency:
+        if not args.no_latency and world == 1:
             lat = call_latency(args.config)
             out["latency_ms"] = lat.get("median_ms")
             out["latency"] = lat
