@@ -111,6 +111,20 @@ int ocvar_hip_results_to_device(OcvarHip* ctx, OcvarMarker* d_markers, int* d_co
  * the block keeps is visible to the receiver.  A gather of 8 records per frame moves 1/8 of the bytes over xGMI. */
 int ocvar_hip_results_to_device_ex(OcvarHip* ctx, OcvarMarker* d_markers, int* d_counts, int max_per_frame, void* stream);
 
+/* Several contexts on one GPU as one detector: n_contexts contexts of chunk_frames frames each (own streams, one shared gate
+ * of gate_width binarise kernels, 0: none) detect a device-resident array of any number of frames chunk by chunk, every context
+ * with one chunk in flight (csrc/pipe.hip: the schedule of bench.py behind the C ABI -- four contexts, gate 2: ~1.4x the
+ * frames/s of one context).  Stateless; results in frame order like ocvar_hip_detect_device.  No counterpart in the reference
+ * (one frame per call); the many-frames form of its per-frame loop, samples/ARTest.cpp:43-82. */
+typedef struct OcvarPipe OcvarPipe;
+int ocvar_hip_pipe_create(OcvarPipe** pipe, int device, int max_width, int max_height, int chunk_frames, int n_contexts, int gate_width);
+void ocvar_hip_pipe_destroy(OcvarPipe* pipe);
+const char* ocvar_hip_pipe_last_error(const OcvarPipe* pipe);
+int ocvar_hip_pipe_set_templates(OcvarPipe* pipe, const OcvarTemplate* templates, int n);
+int ocvar_hip_pipe_set_camera(OcvarPipe* pipe, const OcvarCamera* camera);
+int ocvar_hip_pipe_detect_device(OcvarPipe* pipe, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                 long long n_frames, int grey_in_place, OcvarMarker* markers, int* counts, int max_per_frame);
+
 /* Same, frames in host memory (copied over PCIe first; greyed frames are copied back when requested). */
 int ocvar_hip_detect_host(OcvarHip* ctx, uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,
                           int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts,

@@ -21,7 +21,9 @@ MAX_TEMPLATES, MAX_QUADS, MAX_MARKERS = 16, 256, 64
 
 # every symbol include/ocvar_hip.h declares
 HIP_SYMBOLS = [
-    "ocvar_hip_create", "ocvar_hip_create_ex", "ocvar_hip_capacity_flags", "ocvar_hip_gate_create", "ocvar_hip_gate_destroy", "ocvar_hip_set_gate", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
+    "ocvar_hip_create", "ocvar_hip_create_ex", "ocvar_hip_capacity_flags", "ocvar_hip_gate_create", "ocvar_hip_gate_destroy", "ocvar_hip_set_gate",
+    "ocvar_hip_pipe_create", "ocvar_hip_pipe_destroy", "ocvar_hip_pipe_last_error", "ocvar_hip_pipe_set_templates", "ocvar_hip_pipe_set_camera",
+    "ocvar_hip_pipe_detect_device", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
     "ocvar_hip_detect_device", "ocvar_hip_enqueue", "ocvar_hip_collect", "ocvar_hip_detect_host", "ocvar_hip_find_squares",
     "ocvar_hip_debug_gray", "ocvar_hip_debug_binary", "ocvar_hip_debug_frame_quads", "ocvar_hip_debug_candidates",
     "ocvar_hip_stage_ms", "ocvar_hip_counters", "ocvar_hip_results_to_device", "ocvar_hip_results_to_device_ex", "ocvar_hip_debug_calibrate",
@@ -82,6 +84,14 @@ def hip_lib():
         lib.ocvar_hip_gate_destroy.argtypes = [vp]
         lib.ocvar_hip_gate_destroy.restype = None
         lib.ocvar_hip_set_gate.argtypes = [vp, vp]
+        lib.ocvar_hip_pipe_create.argtypes = [C.POINTER(vp), i, i, i, i, i, i]
+        lib.ocvar_hip_pipe_destroy.argtypes = [vp]
+        lib.ocvar_hip_pipe_destroy.restype = None
+        lib.ocvar_hip_pipe_last_error.argtypes = [vp]
+        lib.ocvar_hip_pipe_last_error.restype = C.c_char_p
+        lib.ocvar_hip_pipe_set_templates.argtypes = [vp, vp, i]
+        lib.ocvar_hip_pipe_set_camera.argtypes = [vp, vp]
+        lib.ocvar_hip_pipe_detect_device.argtypes = [vp, vp, i, i, i, sz, C.c_longlong, i, vp, vp, i]
         lib.ocvar_hip_destroy.restype = None
         lib.ocvar_hip_last_error.argtypes = [vp]
         lib.ocvar_hip_last_error.restype = C.c_char_p
@@ -164,6 +174,48 @@ class Gate:
         if getattr(self, "_g", None):
             self._lib.ocvar_hip_gate_destroy(self._g)
             self._g = None
+
+
+class Pipe:
+    """Several contexts on one GPU as one detector (include/ocvar_hip.h: ocvar_hip_pipe_*): device-resident frames, any number
+    of them, detected chunk by chunk with one chunk in flight per context."""
+
+    def __init__(self, max_width, max_height, chunk_frames=2048, n_contexts=4, gate_width=2, device=0):
+        self._lib = hip_lib()
+        self._p = C.c_void_p()
+        rc = self._lib.ocvar_hip_pipe_create(C.byref(self._p), device, max_width, max_height, chunk_frames, n_contexts, gate_width)
+        if rc != 0:
+            msg = self._lib.ocvar_hip_pipe_last_error(self._p).decode() if self._p else ""
+            self.close()
+            raise OcvarError(f"ocvar_hip_pipe_create failed ({rc}): {msg}")
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self._lib.ocvar_hip_pipe_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise OcvarError(f"{what} failed ({rc}): {self._lib.ocvar_hip_pipe_last_error(self._p).decode()}")
+
+    def set_templates(self, templates):
+        arr = (Template * len(templates))(*templates)
+        self._check(self._lib.ocvar_hip_pipe_set_templates(self._p, arr, len(templates)), "pipe_set_templates")
+
+    def set_camera(self, camera):
+        self._check(self._lib.ocvar_hip_pipe_set_camera(self._p, C.byref(camera)), "pipe_set_camera")
+
+    def detect_device(self, d_ptr, width, height, n_frames, row_stride=None, frame_stride=None, grey_in_place=False, max_per_frame=MAX_MARKERS):
+        row_stride = row_stride or 3 * width
+        frame_stride = frame_stride or row_stride * height
+        markers = np.zeros((n_frames, max_per_frame), MARKER_DTYPE)
+        counts = np.zeros(n_frames, np.int32)
+        self._check(self._lib.ocvar_hip_pipe_detect_device(self._p, d_ptr, width, height, row_stride, frame_stride, n_frames,
+                                                           int(grey_in_place), _ptr(markers), _ptr(counts), max_per_frame), "pipe_detect_device")
+        return markers, counts
 
 
 class Detector:

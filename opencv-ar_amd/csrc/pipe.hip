@@ -1,0 +1,122 @@
+// pipe.hip -- several contexts on one GPU as one detector (include/ocvar_hip.h: ocvar_hip_pipe_*).
+//
+// One context runs a batch as 12 kernels back to back; its latency-bound border followers leave the memory pipeline idle and
+// its streaming binarise kernels leave the followers' slots idle.  Several contexts in flight fill each other's gaps (DESIGN.md
+// section 6: four contexts with at most two binarise kernels at a time reach 1.4x the frames/s of one).  bench.py does that
+// orchestration in Python; this file is the same schedule behind the C ABI for C/C++ callers that hold many frames on the
+// device: the frames are cut into chunks, the chunks go round the contexts, every context has one chunk in flight on its own
+// stream, the first chunks are shortened so that the contexts do not run in lock-step, and the host only ever waits for the
+// context whose chunk is oldest.  Built on the public entry points only (ocvar_hip_create / enqueue / collect / gate).
+#include "ocvar_hip.h"
+#include <hip/hip_runtime.h>
+#include <new>
+#include <string>
+#include <vector>
+
+struct OcvarPipe {
+    int device = 0, n_ctx = 0, chunk = 0;
+    std::vector<OcvarHip*> ctx;
+    OcvarGate* gate = nullptr;
+    std::string err;
+};
+
+extern "C" void ocvar_hip_pipe_destroy(OcvarPipe* p) {
+    if (!p) return;
+    for (OcvarHip* c : p->ctx) ocvar_hip_destroy(c);
+    ocvar_hip_gate_destroy(p->gate);
+    delete p;
+}
+
+extern "C" int ocvar_hip_pipe_create(OcvarPipe** out, int device, int max_width, int max_height, int chunk_frames, int n_contexts,
+                                     int gate_width) {
+    if (!out || chunk_frames < 1 || n_contexts < 1 || n_contexts > 16 || gate_width < 0) return OCVAR_E_ARG;
+    *out = nullptr;
+    OcvarPipe* p = new (std::nothrow) OcvarPipe();
+    if (!p) return OCVAR_E_HIP;
+    *out = p;   // returned even on failure below so that the caller can read the error text, then destroy
+    p->device = device;
+    p->n_ctx = n_contexts;
+    p->chunk = chunk_frames;
+    if (gate_width > 0 && n_contexts > 1) {
+        const int rc = ocvar_hip_gate_create(&p->gate, device, gate_width);
+        if (rc) { p->err = "ocvar_hip_gate_create failed"; return rc; }
+    }
+    for (int i = 0; i < n_contexts; i++) {
+        OcvarHip* c = nullptr;
+        const int rc = ocvar_hip_create(&c, device, max_width, max_height, chunk_frames);
+        if (c) p->ctx.push_back(c);
+        if (rc) { p->err = c ? ocvar_hip_last_error(c) : "ocvar_hip_create failed"; return rc; }
+        if (p->gate) (void)ocvar_hip_set_gate(c, p->gate);
+    }
+    return OCVAR_OK;
+}
+
+extern "C" const char* ocvar_hip_pipe_last_error(const OcvarPipe* p) { return p ? p->err.c_str() : "null pipe"; }
+
+extern "C" int ocvar_hip_pipe_set_templates(OcvarPipe* p, const OcvarTemplate* t, int n) {
+    if (!p) return OCVAR_E_ARG;
+    for (OcvarHip* c : p->ctx) {
+        const int rc = ocvar_hip_set_templates(c, t, n);
+        if (rc) { p->err = ocvar_hip_last_error(c); return rc; }
+    }
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_pipe_set_camera(OcvarPipe* p, const OcvarCamera* cam) {
+    if (!p) return OCVAR_E_ARG;
+    for (OcvarHip* c : p->ctx) {
+        const int rc = ocvar_hip_set_camera(c, cam);
+        if (rc) { p->err = ocvar_hip_last_error(c); return rc; }
+    }
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_pipe_detect_device(OcvarPipe* p, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                            long long n_frames, int grey_in_place, OcvarMarker* markers, int* counts, int max_per_frame) {
+    if (!p || !d_bgr || n_frames < 1 || !counts || max_per_frame < 0 || (max_per_frame > 0 && !markers)) return OCVAR_E_ARG;
+    const int K = p->n_ctx;
+    struct Flight { long long start = 0; int count = 0; };
+    std::vector<Flight> fl((size_t)K);
+    long long next = 0;
+    int first_err = OCVAR_OK;
+    auto launch = [&](int i, int want) -> int {
+        const long long left = n_frames - next;
+        const int cnt = (int)(left < want ? left : want);
+        fl[i].count = 0;
+        if (cnt <= 0) return OCVAR_OK;
+        const int rc = ocvar_hip_enqueue(p->ctx[i], d_bgr + (size_t)next * frame_stride, width, height, row_stride, frame_stride, cnt,
+                                         grey_in_place, nullptr, nullptr, nullptr);
+        if (rc) { p->err = ocvar_hip_last_error(p->ctx[i]); return rc; }
+        fl[i].start = next;
+        fl[i].count = cnt;
+        next += cnt;
+        return OCVAR_OK;
+    };
+    // the first chunks are (i + 1) / K of a chunk: contexts that start together stay in lock-step, all in the streaming kernels,
+    // then all in the followers
+    for (int i = 0; i < K; i++) {
+        int want = (int)(((long long)p->chunk * (i + 1)) / K);
+        if (want < 1) want = 1;
+        const int rc = launch(i, want);
+        if (rc && !first_err) first_err = rc;
+    }
+    for (bool any = true; any;) {
+        any = false;
+        for (int i = 0; i < K; i++) {
+            if (fl[i].count == 0) continue;
+            any = true;
+            const int rc = ocvar_hip_collect(p->ctx[i], markers ? markers + (size_t)fl[i].start * max_per_frame : nullptr,
+                                             counts + fl[i].start, max_per_frame);
+            if (rc && !first_err) {   // keep draining the other contexts; report the first failure
+                first_err = rc;
+                p->err = ocvar_hip_last_error(p->ctx[i]);
+            }
+            fl[i].count = 0;
+            if (!first_err) {
+                const int rc2 = launch(i, p->chunk);
+                if (rc2 && !first_err) first_err = rc2;
+            }
+        }
+    }
+    return first_err;
+}

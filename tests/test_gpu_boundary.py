@@ -301,3 +301,29 @@ def test_contexts_sharing_a_gate_give_the_same_results():
     gated = run(oa.Gate(1))
     assert plain == gated
     assert all(np.frombuffer(c, np.int32).min() >= 1 for _, c in plain)
+
+
+def test_pipe_of_contexts_equals_one_context():
+    """ocvar_hip_pipe_*: the frames of one device array cut into chunks that go round three gated contexts (ragged first
+    chunks, a last partial chunk) -- same markers and counts, frame by frame, as one context detecting them in one batch."""
+    import torch
+    import opencv_ar_amd as oa
+    cfg = H.synth_config(2)
+    names = ["2x2-01"]
+    n = 29
+    tpls = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, x + ".png") for x in names])
+    cam = oa.default_camera(cfg.width, cfg.height)
+    frames = np.stack([H.synth_frame(cfg, 7 * f, names)[0] for f in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    det = oa.Detector(cfg.width, cfg.height, max_batch=n)
+    det.set_templates(tpls)
+    det.set_camera(cam)
+    m1, c1 = det.detect_device(d.data_ptr(), cfg.width, cfg.height, n, max_per_frame=8)
+    pipe = oa.Pipe(cfg.width, cfg.height, chunk_frames=4, n_contexts=3, gate_width=1)
+    pipe.set_templates(tpls)
+    pipe.set_camera(cam)
+    for _ in range(2):
+        m2, c2 = pipe.detect_device(d.data_ptr(), cfg.width, cfg.height, n, max_per_frame=8)
+        assert c1.tobytes() == c2.tobytes() and c1.min() >= 1
+        assert m1.tobytes() == m2.tobytes()
