@@ -79,7 +79,8 @@ int ocvar_hip_capacity_flags(const OcvarHip* ctx);
 typedef struct OcvarGate OcvarGate;
 int ocvar_hip_gate_create(OcvarGate** gate, int device, int width);
 void ocvar_hip_gate_destroy(OcvarGate* gate);
-/* gate may be NULL (no gate: the default).  The gate must outlive the batches enqueued under it. */
+/* gate may be NULL (no gate: the default).  The gate must outlive the batches enqueued under it; it keeps its order on the
+ * host without locks, so the contexts that share one are enqueued from one host thread. */
 int ocvar_hip_set_gate(OcvarHip* ctx, OcvarGate* gate);
 
 int ocvar_hip_set_templates(OcvarHip* ctx, const OcvarTemplate* templates, int n);
