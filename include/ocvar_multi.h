@@ -6,9 +6,10 @@
  * C/C++ caller that owns several frames at once (independent frames are the shards, "one process with
  * ncclCommInitAll"; BASELINE.json configs[3]: frame f -> GPU f mod N, RCCL gather of the CvarMarker arrays).  Each device
  * runs the single-GPU path of include/ocvar_hip.h on its frames; there is no data-path collective.  The only exchange is
- * ONE ncclGather (/opt/rocm/include/rccl/rccl.h:745) of the fixed-size result block per batch -- [frames][OCVAR_MAX_MARKERS]
- * marker records followed by [frames] counts, as bytes -- to the root device, which copies it to the host and puts the
- * frames back in caller order.  The messages are small (12 KB per frame): latency-bound, so one collective per batch.
+ * ONE ncclGather (/opt/rocm/include/rccl/rccl.h:745) of the fixed-size result block per batch -- [frames][k] marker records,
+ * k = the max_per_frame of the call (at most OCVAR_MAX_MARKERS), followed by [frames] full counts, as bytes -- to the root
+ * device, which copies it to the host and puts the frames back in caller order.  The messages are small (184 B per record:
+ * 1.5 KB per frame at 8 records, 12 KB at 64): latency-bound, so one collective per batch.
  *
  * Plain pointers and sizes; returns 0 or a negative OCVAR_E_* code (ocvar_hip.h); none throws.
  */

@@ -28,7 +28,7 @@ struct OcvarMulti {
 
 namespace {
 constexpr int MAXM = OCVAR_MAX_MARKERS;
-size_t marker_bytes(int frames) { return (size_t)frames * MAXM * sizeof(OcvarMarker); }
+size_t marker_bytes(int frames, int per_frame = MAXM) { return (size_t)frames * per_frame * sizeof(OcvarMarker); }
 
 #define M_HIP(m, call)                                                              \
     do {                                                                            \
@@ -129,6 +129,10 @@ extern "C" int ocvar_multi_detect_device(OcvarMulti* m, uint8_t* const* d_bgr, i
     const int N = m->n;
     for (int d = 0; d < N; d++)
         if (n_local[d] < 0 || n_local[d] > m->max_local || (n_local[d] > 0 && !d_bgr[d])) return OCVAR_E_ARG;
+    // The blocks carry the first K records of every frame -- as many as the caller takes per frame -- and the frames' full
+    // counts (ocvar_hip_results_to_device_ex): a caller that keeps 8 markers per frame gathers 1.5 KB per frame instead of 12.
+    const int K = max_per_frame < 1 ? 1 : (max_per_frame > MAXM ? MAXM : max_per_frame);
+    const size_t block_bytes = marker_bytes(m->max_local, K) + (size_t)m->max_local * sizeof(int);   // <= m->block_bytes (K = MAXM)
     // every device: detect its share (all kernels of the single-GPU path on the device's own stream), then put the result
     // block into the send buffer behind them
     for (int d = 0; d < N; d++) {
@@ -136,15 +140,15 @@ extern "C" int ocvar_multi_detect_device(OcvarMulti* m, uint8_t* const* d_bgr, i
         M_HIP(m, hipSetDevice(m->dev[d]));
         int rc = ocvar_hip_enqueue(m->ctx[d], d_bgr[d], width, height, row_stride, frame_stride, n_local[d], 0, nullptr, nullptr, m->stream[d]);
         if (rc) { m->err = ocvar_hip_last_error(m->ctx[d]); return rc; }
-        rc = ocvar_hip_results_to_device(m->ctx[d], reinterpret_cast<OcvarMarker*>(m->d_block[d]),
-                                         reinterpret_cast<int*>(m->d_block[d] + marker_bytes(m->max_local)), m->stream[d]);
+        rc = ocvar_hip_results_to_device_ex(m->ctx[d], reinterpret_cast<OcvarMarker*>(m->d_block[d]),
+                                            reinterpret_cast<int*>(m->d_block[d] + marker_bytes(m->max_local, K)), K, m->stream[d]);
         if (rc) { m->err = ocvar_hip_last_error(m->ctx[d]); return rc; }
     }
     // one gather of the fixed-size blocks to the root (device 0 of the list); a single-thread caller issues all ranks'
     // calls inside one group
     M_NCCL(m, ncclGroupStart());
     for (int d = 0; d < N; d++) {
-        const ncclResult_t r = ncclGather(m->d_block[d], d == 0 ? m->d_all : nullptr, m->block_bytes, ncclUint8, 0, m->comm[d], m->stream[d]);
+        const ncclResult_t r = ncclGather(m->d_block[d], d == 0 ? m->d_all : nullptr, block_bytes, ncclUint8, 0, m->comm[d], m->stream[d]);
         if (r != ncclSuccess) {
             (void)ncclGroupEnd();
             m->err = std::string("ncclGather: ") + ncclGetErrorString(r);
@@ -153,7 +157,7 @@ extern "C" int ocvar_multi_detect_device(OcvarMulti* m, uint8_t* const* d_bgr, i
     }
     M_NCCL(m, ncclGroupEnd());
     M_HIP(m, hipSetDevice(m->dev[0]));
-    M_HIP(m, hipMemcpyAsync(m->h_all, m->d_all, m->block_bytes * N, hipMemcpyDeviceToHost, m->stream[0]));
+    M_HIP(m, hipMemcpyAsync(m->h_all, m->d_all, block_bytes * N, hipMemcpyDeviceToHost, m->stream[0]));
     // collect per device (reports capacity errors of that device's batch), root last: its stream carries the copy-out
     int first_err = OCVAR_OK;
     std::vector<int> scratch_counts((size_t)m->max_local);
@@ -171,15 +175,15 @@ extern "C" int ocvar_multi_detect_device(OcvarMulti* m, uint8_t* const* d_bgr, i
     if (first_err) return first_err;
     // root: blocks in rank order -> caller order (global frame d + N*i)
     for (int d = 0; d < N; d++) {
-        const uint8_t* blk = m->h_all + (size_t)d * m->block_bytes;
+        const uint8_t* blk = m->h_all + (size_t)d * block_bytes;
         const OcvarMarker* mk = reinterpret_cast<const OcvarMarker*>(blk);
-        const int* cn = reinterpret_cast<const int*>(blk + marker_bytes(m->max_local));
+        const int* cn = reinterpret_cast<const int*>(blk + marker_bytes(m->max_local, K));
         for (int i = 0; i < n_local[d]; i++) {
             const size_t g = (size_t)d + (size_t)N * i;
             counts[g] = cn[i];
             int k = cn[i] < max_per_frame ? cn[i] : max_per_frame;
-            if (k > MAXM) k = MAXM;
-            if (k > 0) std::memcpy(markers + g * max_per_frame, mk + (size_t)i * MAXM, (size_t)k * sizeof(OcvarMarker));
+            if (k > K) k = K;
+            if (k > 0) std::memcpy(markers + g * max_per_frame, mk + (size_t)i * K, (size_t)k * sizeof(OcvarMarker));
         }
     }
     return OCVAR_OK;
