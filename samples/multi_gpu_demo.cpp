@@ -88,6 +88,22 @@ int main(int argc, char** argv) {
         if (std::memcmp(&mk[(size_t)f * OCVAR_MAX_MARKERS], &ref[(size_t)f * OCVAR_MAX_MARKERS], (size_t)k * sizeof(OcvarMarker)) != 0) mismatches++;
     }
     ocvar_hip_destroy(one);
+    // narrow blocks: a caller that keeps 2 markers per frame gathers 2 records per frame; the counts stay the full counts
+    {
+        const int K = 2;
+        std::vector<OcvarMarker> mk2((size_t)F * K);
+        std::vector<int> cn2(F);
+        rc = ocvar_multi_detect_host(m, frames.data(), cfg.width, cfg.height, cfg.width * 3, fb, F, mk2.data(), cn2.data(), K);
+        if (rc) {
+            std::fprintf(stderr, "ocvar_multi_detect_host (2 per frame) failed (%d): %s\n", rc, ocvar_multi_last_error(m));
+            return 1;
+        }
+        for (int f = 0; f < F; f++) {
+            if (cn2[f] != cref[f]) { mismatches++; continue; }
+            const int k = cn2[f] < K ? cn2[f] : K;
+            if (std::memcmp(&mk2[(size_t)f * K], &ref[(size_t)f * OCVAR_MAX_MARKERS], (size_t)k * sizeof(OcvarMarker)) != 0) mismatches++;
+        }
+    }
 
     // timing with the shards resident on the devices (frames d, d+N, ... on device d)
     std::vector<uint8_t*> d_bgr(N, nullptr);
