@@ -150,6 +150,7 @@ def main():
         det.set_camera(camera)
         if gate is not None:
             det.set_gate(gate)
+        det.set_result_limit(8)   # what collect(8) takes: 3 MB instead of 24 MB of marker records per 2048-frame launch
         dets.append(det)
         streams.append(torch.cuda.Stream())
     det = dets[0]

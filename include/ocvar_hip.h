@@ -102,6 +102,13 @@ int ocvar_hip_detect_device(OcvarHip* ctx, uint8_t* d_bgr, int width, int height
 int ocvar_hip_enqueue(OcvarHip* ctx, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
                       int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts, void* stream);
 int ocvar_hip_collect(OcvarHip* ctx, OcvarMarker* markers, int* counts, int max_per_frame);
+/* 1 if the enqueued batch has finished (ocvar_hip_collect will not wait), 0 if it is still running, < 0 on error or when
+ * nothing is enqueued.  A caller with several contexts in flight collects the one that is ready first. */
+int ocvar_hip_ready(OcvarHip* ctx);
+/* How many marker records per frame a batch brings to the host (1 .. OCVAR_MAX_MARKERS, the default): the copy-out of a
+ * 2048-frame batch is 24 MB at 64 records per frame, 3 MB at 8.  ocvar_hip_collect returns at most this many per frame;
+ * the counts are always the frames' full counts. */
+int ocvar_hip_set_result_limit(OcvarHip* ctx, int max_per_frame);
 
 /* After ocvar_hip_enqueue: stream-ordered device-to-device copy of the batch's results into caller-owned device
  * buffers, d_markers [n_frames][OCVAR_MAX_MARKERS] and d_counts [n_frames] -- for callers that gather results

@@ -21,7 +21,7 @@ MAX_TEMPLATES, MAX_QUADS, MAX_MARKERS = 16, 256, 64
 
 # every symbol include/ocvar_hip.h declares
 HIP_SYMBOLS = [
-    "ocvar_hip_create", "ocvar_hip_create_ex", "ocvar_hip_capacity_flags", "ocvar_hip_gate_create", "ocvar_hip_gate_destroy", "ocvar_hip_set_gate",
+    "ocvar_hip_create", "ocvar_hip_create_ex", "ocvar_hip_capacity_flags", "ocvar_hip_gate_create", "ocvar_hip_gate_destroy", "ocvar_hip_set_gate", "ocvar_hip_ready", "ocvar_hip_set_result_limit",
     "ocvar_hip_pipe_create", "ocvar_hip_pipe_destroy", "ocvar_hip_pipe_last_error", "ocvar_hip_pipe_set_templates", "ocvar_hip_pipe_set_camera",
     "ocvar_hip_pipe_detect_device", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
     "ocvar_hip_detect_device", "ocvar_hip_enqueue", "ocvar_hip_collect", "ocvar_hip_detect_host", "ocvar_hip_find_squares",
@@ -84,6 +84,8 @@ def hip_lib():
         lib.ocvar_hip_gate_destroy.argtypes = [vp]
         lib.ocvar_hip_gate_destroy.restype = None
         lib.ocvar_hip_set_gate.argtypes = [vp, vp]
+        lib.ocvar_hip_ready.argtypes = [vp]
+        lib.ocvar_hip_set_result_limit.argtypes = [vp, i]
         lib.ocvar_hip_pipe_create.argtypes = [C.POINTER(vp), i, i, i, i, i, i]
         lib.ocvar_hip_pipe_destroy.argtypes = [vp]
         lib.ocvar_hip_pipe_destroy.restype = None
@@ -285,6 +287,17 @@ class Detector:
         counts = np.zeros(n, np.int32)
         self._check(self._lib.ocvar_hip_collect(self._ctx, _ptr(markers), _ptr(counts), max_per_frame), "collect")
         return markers, counts
+
+    def ready(self):
+        """True once the enqueued batch has finished (collect() will not wait)"""
+        rc = self._lib.ocvar_hip_ready(self._ctx)
+        if rc < 0:
+            self._check(rc, "ready")
+        return rc == 1
+
+    def set_result_limit(self, max_per_frame):
+        """marker records per frame a batch brings to the host (default MAX_MARKERS); counts stay the full counts"""
+        self._check(self._lib.ocvar_hip_set_result_limit(self._ctx, max_per_frame), "set_result_limit")
 
     def set_gate(self, gate):
         """share a Gate with other detectors on the same GPU (None removes it); the detector keeps the gate alive"""

@@ -31,6 +31,7 @@ struct OcvarGate {
 struct OcvarHip {
     int device = 0;
     OcvarGate* gate = nullptr;
+    int result_limit = OCVAR_MAX_MARKERS;   // marker records per frame copied to the host (ocvar_hip_set_result_limit)
     Workspace ws{};
     hipStream_t stream = nullptr;
     hipStream_t hp_stream = nullptr;   // high-priority stream of the latency-bound kernels (env OCVAR_SPLIT_STREAMS=1; default off)
@@ -411,7 +412,11 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
         TRACE_LAUNCH("finalise", f);
         HIP_TRY(c, hop(11, f, s));
         HIP_TRY(c, hipMemcpyAsync(c->h_counts, w.n_markers, n_frames * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(c->h_markers, w.markers, (size_t)n_frames * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToHost, s));
+        if (c->result_limit >= MAXM)
+            HIP_TRY(c, hipMemcpyAsync(c->h_markers, w.markers, (size_t)n_frames * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToHost, s));
+        else   // the first result_limit records of every frame, at their usual places in the host block
+            HIP_TRY(c, hipMemcpy2DAsync(c->h_markers, (size_t)MAXM * sizeof(MarkerRec), w.markers, (size_t)MAXM * sizeof(MarkerRec),
+                                        (size_t)c->result_limit * sizeof(MarkerRec), (size_t)n_frames, hipMemcpyDeviceToHost, s));
     } else {
         HIP_TRY(c, hop(5, f, s));
         for (int k = 6; k < 12; k++) HIP_TRY(c, hipEventRecord(c->ev[k], s));
@@ -479,9 +484,27 @@ extern "C" int ocvar_hip_collect(OcvarHip* c, OcvarMarker* markers, int* counts,
     for (int f = 0; f < n; f++) {
         counts[f] = c->h_counts[f];
         int k = counts[f] < max_per_frame ? counts[f] : max_per_frame;
-        if (k > MAXM) k = MAXM;
+        if (k > c->result_limit) k = c->result_limit;
         if (k > 0) std::memcpy(markers + (size_t)f * max_per_frame, c->h_markers + (size_t)f * MAXM, k * sizeof(OcvarMarker));
     }
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_ready(OcvarHip* c) {
+    if (!c || !c->pending) return OCVAR_E_ARG;
+    const hipError_t e = hipEventQuery(c->ev[12]);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    c->err = std::string("hipEventQuery: ") + hipGetErrorString(e);
+    return OCVAR_E_HIP;
+}
+
+extern "C" int ocvar_hip_set_result_limit(OcvarHip* c, int max_per_frame) {
+    if (!c || c->pending || max_per_frame < 1 || max_per_frame > MAXM) return OCVAR_E_ARG;
+    c->result_limit = max_per_frame;
     return OCVAR_OK;
 }
 

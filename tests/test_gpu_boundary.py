@@ -327,3 +327,35 @@ def test_pipe_of_contexts_equals_one_context():
         m2, c2 = pipe.detect_device(d.data_ptr(), cfg.width, cfg.height, n, max_per_frame=8)
         assert c1.tobytes() == c2.tobytes() and c1.min() >= 1
         assert m1.tobytes() == m2.tobytes()
+
+
+def test_ready_and_result_limit():
+    """ocvar_hip_ready turns 1 once the batch is done (collect then returns at once); a result limit of 2 records per frame
+    brings the first two markers of every frame to the host and leaves the counts alone."""
+    import time
+    import torch
+    import opencv_ar_amd as oa
+    cfg = H.synth_config(3, width=800, height=600, grid_x=3, grid_y=2)
+    n = 6
+    tpls = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, x + ".png") for x in H.TEMPLATE_ORDER])
+    cam = oa.default_camera(cfg.width, cfg.height)
+    frames = np.stack([H.synth_frame(cfg, 300 + f)[0] for f in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    det = oa.Detector(cfg.width, cfg.height, max_batch=n)
+    det.set_templates(tpls)
+    det.set_camera(cam)
+    full_m, full_c = det.detect_device(d.data_ptr(), cfg.width, cfg.height, n)
+    assert full_c.max() >= 2
+    det.set_result_limit(2)
+    det.enqueue_device(d.data_ptr(), cfg.width, cfg.height, n)
+    t0 = time.time()
+    while not det.ready():
+        assert time.time() - t0 < 30
+        time.sleep(1e-3)
+    m, c = det.collect(8)
+    assert c.tobytes() == full_c.tobytes()
+    for f in range(n):
+        k = min(int(c[f]), 2)
+        assert m[f, :k].tobytes() == full_m[f, :k].tobytes()
+        assert not m[f, k:].tobytes().strip(b"\0")   # nothing beyond the limit reaches the caller
