@@ -102,6 +102,14 @@ int ocvar_hip_detect_device(OcvarHip* ctx, uint8_t* d_bgr, int width, int height
 int ocvar_hip_enqueue(OcvarHip* ctx, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
                       int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts, void* stream);
 int ocvar_hip_collect(OcvarHip* ctx, OcvarMarker* markers, int* counts, int max_per_frame);
+/* ocvar_hip_enqueue with the previous markers in DEVICE memory: d_prev [n_frames][OCVAR_MAX_MARKERS], d_prev_counts [n_frames]
+ * (counts above OCVAR_MAX_MARKERS are read as OCVAR_MAX_MARKERS), e.g. the block ocvar_hip_results_to_device wrote for the
+ * same streams one time step earlier -- the tracking state of a block of video streams (the caller-owned `markers` vector of
+ * cvarArMultRegistration, /root/reference/src/opencvar.cpp:635-668, samples/ARTest.cpp:57) then never leaves the device.
+ * The copy into the context is stream-ordered: the arrays may be overwritten by ocvar_hip_results_to_device of the same
+ * batch. */
+int ocvar_hip_enqueue_tracked(OcvarHip* ctx, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                              int n_frames, int grey_in_place, const OcvarMarker* d_prev, const int* d_prev_counts, void* stream);
 /* 1 if the enqueued batch has finished (ocvar_hip_collect will not wait), 0 if it is still running, < 0 on error or when
  * nothing is enqueued.  A caller with several contexts in flight collects the one that is ready first. */
 int ocvar_hip_ready(OcvarHip* ctx);
@@ -109,6 +117,17 @@ int ocvar_hip_ready(OcvarHip* ctx);
  * 2048-frame batch is 24 MB at 64 records per frame, 3 MB at 8.  ocvar_hip_collect returns at most this many per frame;
  * the counts are always the frames' full counts. */
 int ocvar_hip_set_result_limit(OcvarHip* ctx, int max_per_frame);
+
+/* Launch parameters that change how the work is cut, never what comes out (every value gives bit-identical results; the
+ * defaults are the measured optimum for the batch size).  value 0 restores the default.  The product library reads no tuning
+ * from the environment; only builds made with -DOCVAR_PROF (`make prof`) also honour OCVAR_* variables of the same names. */
+enum { OCVAR_TUNE_CROP_PHASES = 1, /* crop-pass tier 2 in 1 launch or 2 (exact pruning behind the crop's best quad) */
+       OCVAR_TUNE_MID_STEPS = 2,   /* step budget of follower tier 2 before a border goes to the wave tier (>= 32) */
+       OCVAR_TUNE_MID_BLOCKS = 3, OCVAR_TUNE_LONG_BLOCKS = 4, OCVAR_TUNE_SHORT_BLOCKS = 5, /* grids of tiers 2, 3, 1 */
+       OCVAR_TUNE_MIN_UNITS = 6 }; /* binarise work units per launch below which row chunks are not made taller */
+int ocvar_hip_set_tuning(OcvarHip* ctx, int knob, int value);
+/* How the library was built: "... product(...)" or "... OCVAR_PROF(...)" -- bench.py prints it with its number. */
+const char* ocvar_hip_build_info(void);
 
 /* After ocvar_hip_enqueue: stream-ordered device-to-device copy of the batch's results into caller-owned device
  * buffers, d_markers [n_frames][OCVAR_MAX_MARKERS] and d_counts [n_frames] -- for callers that gather results
@@ -132,6 +151,14 @@ int ocvar_hip_pipe_set_templates(OcvarPipe* pipe, const OcvarTemplate* templates
 int ocvar_hip_pipe_set_camera(OcvarPipe* pipe, const OcvarCamera* camera);
 int ocvar_hip_pipe_detect_device(OcvarPipe* pipe, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
                                  long long n_frames, int grey_in_place, OcvarMarker* markers, int* counts, int max_per_frame);
+/* Stateful form (the reference's behaviour over video: `markers` persists across calls, opencvar.cpp:635-668): one call = one
+ * time step of n_streams video streams, frame s of d_bgr being stream s's current frame.  Every stream's markers of the
+ * previous step are its tracking input; they are kept by the pipe in device memory between calls (never copied to the host
+ * and back).  reset != 0 (or a different n_streams than the last call): the streams start with no markers, i.e. a stateless
+ * first step.  Streams are independent, so chunks of streams go round the contexts as chunks of frames do above; results in
+ * stream order. */
+int ocvar_hip_pipe_track_device(OcvarPipe* pipe, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                long long n_streams, int grey_in_place, int reset, OcvarMarker* markers, int* counts, int max_per_frame);
 
 /* Same, frames in host memory (copied over PCIe first; greyed frames are copied back when requested). */
 int ocvar_hip_detect_host(OcvarHip* ctx, uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,

@@ -47,6 +47,16 @@ int ocvar_multi_detect_host(OcvarMulti* m, const uint8_t* h_bgr, int width, int 
 int ocvar_multi_detect_device(OcvarMulti* m, uint8_t* const* d_bgr, int width, int height, int row_stride, size_t frame_stride,
                               const int* n_local, OcvarMarker* markers, int* counts, int max_per_frame);
 
+/* Stateful form: one call = one time step of n_streams video streams (frame s = stream s's current frame); stream s lives on
+ * device s mod n_devices, local slot s / n_devices, for as long as the tracker is used, and its markers of the previous step
+ * -- the tracking input of cvarArMultRegistration, /root/reference/src/opencvar.cpp:635-668 -- stay in that device's memory
+ * between calls ("stateful tracking is sequential per stream: shard by stream").  reset != 0: the streams
+ * start without markers (a stateless first step).  The gather is the same single ncclGather per step. */
+int ocvar_multi_track_host(OcvarMulti* m, const uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,
+                           int n_streams, int reset, OcvarMarker* markers, int* counts, int max_per_frame);
+int ocvar_multi_track_device(OcvarMulti* m, uint8_t* const* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                             const int* n_local, int reset, OcvarMarker* markers, int* counts, int max_per_frame);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ MAX_TEMPLATES, MAX_QUADS, MAX_MARKERS = 16, 256, 64
 HIP_SYMBOLS = [
     "ocvar_hip_create", "ocvar_hip_create_ex", "ocvar_hip_capacity_flags", "ocvar_hip_gate_create", "ocvar_hip_gate_destroy", "ocvar_hip_set_gate", "ocvar_hip_ready", "ocvar_hip_set_result_limit",
     "ocvar_hip_pipe_create", "ocvar_hip_pipe_destroy", "ocvar_hip_pipe_last_error", "ocvar_hip_pipe_set_templates", "ocvar_hip_pipe_set_camera",
-    "ocvar_hip_pipe_detect_device", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
+    "ocvar_hip_pipe_detect_device", "ocvar_hip_pipe_track_device", "ocvar_hip_enqueue_tracked", "ocvar_hip_build_info", "ocvar_hip_set_tuning", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
     "ocvar_hip_detect_device", "ocvar_hip_enqueue", "ocvar_hip_collect", "ocvar_hip_detect_host", "ocvar_hip_find_squares",
     "ocvar_hip_debug_gray", "ocvar_hip_debug_binary", "ocvar_hip_debug_frame_quads", "ocvar_hip_debug_candidates",
     "ocvar_hip_stage_ms", "ocvar_hip_counters", "ocvar_hip_results_to_device", "ocvar_hip_results_to_device_ex", "ocvar_hip_debug_calibrate",
@@ -94,6 +94,11 @@ def hip_lib():
         lib.ocvar_hip_pipe_set_templates.argtypes = [vp, vp, i]
         lib.ocvar_hip_pipe_set_camera.argtypes = [vp, vp]
         lib.ocvar_hip_pipe_detect_device.argtypes = [vp, vp, i, i, i, sz, C.c_longlong, i, vp, vp, i]
+        lib.ocvar_hip_pipe_track_device.argtypes = [vp, vp, i, i, i, sz, C.c_longlong, i, i, vp, vp, i]
+        lib.ocvar_hip_enqueue_tracked.argtypes = [vp, vp, i, i, i, sz, i, i, vp, vp, vp]
+        lib.ocvar_hip_set_tuning.argtypes = [vp, i, i]
+        lib.ocvar_hip_build_info.argtypes = []
+        lib.ocvar_hip_build_info.restype = C.c_char_p
         lib.ocvar_hip_destroy.restype = None
         lib.ocvar_hip_last_error.argtypes = [vp]
         lib.ocvar_hip_last_error.restype = C.c_char_p
@@ -219,6 +224,22 @@ class Pipe:
                                                            int(grey_in_place), _ptr(markers), _ptr(counts), max_per_frame), "pipe_detect_device")
         return markers, counts
 
+    def track_device(self, d_ptr, width, height, n_streams, reset=False, row_stride=None, frame_stride=None, grey_in_place=False,
+                     max_per_frame=MAX_MARKERS):
+        """one time step of n_streams video streams (frame s = stream s); the streams' markers of the previous step stay on the device"""
+        row_stride = row_stride or 3 * width
+        frame_stride = frame_stride or row_stride * height
+        markers = np.zeros((n_streams, max_per_frame), MARKER_DTYPE)
+        counts = np.zeros(n_streams, np.int32)
+        self._check(self._lib.ocvar_hip_pipe_track_device(self._p, d_ptr, width, height, row_stride, frame_stride, n_streams,
+                                                          int(grey_in_place), int(reset), _ptr(markers), _ptr(counts), max_per_frame), "pipe_track_device")
+        return markers, counts
+
+
+def build_info():
+    """how libocvar_hip.so was built (flags that change what the kernels do: profiling hooks, tuning switches)"""
+    return hip_lib().ocvar_hip_build_info().decode()
+
 
 class Detector:
     """A device context: batches of frames -> CvarMarker arrays (cvarArMultRegistration semantics per frame)."""
@@ -298,6 +319,13 @@ class Detector:
     def set_result_limit(self, max_per_frame):
         """marker records per frame a batch brings to the host (default MAX_MARKERS); counts stay the full counts"""
         self._check(self._lib.ocvar_hip_set_result_limit(self._ctx, max_per_frame), "set_result_limit")
+
+    TUNE = {"crop_phases": 1, "mid_steps": 2, "mid_blocks": 3, "long_blocks": 4, "short_blocks": 5, "min_units": 6}
+
+    def set_tuning(self, **kw):
+        """result-invariant launch parameters (include/ocvar_hip.h: OCVAR_TUNE_*); 0 restores a default"""
+        for k, v in kw.items():
+            self._check(self._lib.ocvar_hip_set_tuning(self._ctx, self.TUNE[k], int(v)), f"set_tuning({k})")
 
     def set_gate(self, gate):
         """share a Gate with other detectors on the same GPU (None removes it); the detector keeps the gate alive"""

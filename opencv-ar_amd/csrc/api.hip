@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace ocvar;
@@ -32,6 +33,7 @@ struct OcvarHip {
     int device = 0;
     OcvarGate* gate = nullptr;
     int result_limit = OCVAR_MAX_MARKERS;   // marker records per frame copied to the host (ocvar_hip_set_result_limit)
+    int tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ocvar_hip_set_tuning: 0 = default
     Workspace ws{};
     hipStream_t stream = nullptr;
     hipStream_t hp_stream = nullptr;   // high-priority stream of the latency-bound kernels (env OCVAR_SPLIT_STREAMS=1; default off)
@@ -40,8 +42,8 @@ struct OcvarHip {
     std::vector<void*> allocs;
     uint8_t* d_frames = nullptr;  // staging for the host-buffer entry points
     size_t d_frames_bytes = 0;
-    uint8_t* h_stage = nullptr;   // page-locked bounce buffer of the small-call path of ocvar_hip_detect_host
-    size_t h_stage_bytes = 0;
+    uint8_t* h_stage[2] = {nullptr, nullptr};   // page-locked staging of the host entry points (double buffer)
+    size_t h_stage_bytes = 0;                   // size of each
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;   // host transport of ocvar_hip_detect_host (created on first use)
     std::vector<hipEvent_t> h2d_done;
     hipEvent_t computed = nullptr;
@@ -98,7 +100,8 @@ extern "C" int ocvar_hip_create_ex(OcvarHip** out, int device, int max_width, in
     c->device = device;
     HIP_TRY(c, hipSetDevice(device));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    {
+#ifdef OCVAR_PROF
+    {   // (an experiment kept for profiling builds: measured with 4 contexts, no gain -- see enqueue_impl)
         const char* e = std::getenv("OCVAR_SPLIT_STREAMS");
         if (e && std::atoi(e) != 0) {
             int lo = 0, hi = 0;
@@ -106,6 +109,7 @@ extern "C" int ocvar_hip_create_ex(OcvarHip** out, int device, int max_width, in
             HIP_TRY(c, hipStreamCreateWithPriority(&c->hp_stream, hipStreamNonBlocking, hi));
         }
     }
+#endif
     for (auto& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
     Workspace& w = c->ws;
     w.max_w = max_width;
@@ -181,7 +185,8 @@ extern "C" void ocvar_hip_destroy(OcvarHip* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->d_frames) (void)hipFree(c->d_frames);
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (auto p : c->h_stage)
+        if (p) (void)hipHostFree(p);
     if (c->h_markers) (void)hipHostFree(c->h_markers);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_prev) (void)hipHostFree(c->h_prev);
@@ -267,6 +272,38 @@ extern "C" int ocvar_hip_set_camera(OcvarHip* c, const OcvarCamera* cam) {
     return OCVAR_OK;
 }
 
+// A result-invariant launch parameter: the context's own setting (ocvar_hip_set_tuning), else the default.  Profiling builds
+// (-DOCVAR_PROF) also listen to the environment variable of the same purpose; the product library reads no tuning from the
+// environment, so a benchmark number cannot depend on the caller's shell.
+static long long tuned(const OcvarHip* c, int knob, const char* env_name, long long dflt) {
+    if (knob > 0 && knob < 8 && c->tune[knob] > 0) return c->tune[knob];
+#ifdef OCVAR_PROF
+    if (const char* e = std::getenv(env_name)) return std::atoll(e);
+#else
+    (void)env_name;
+#endif
+    return dflt;
+}
+
+extern "C" int ocvar_hip_set_tuning(OcvarHip* c, int knob, int value) {
+    if (!c || knob < 1 || knob > 6 || value < 0 || c->pending) return OCVAR_E_ARG;
+    c->tune[knob] = value;
+    return OCVAR_OK;
+}
+
+extern "C" const char* ocvar_hip_build_info(void) {
+    return "libocvar_hip gfx950"
+#ifdef OCVAR_NBR_TILED
+           " OCVAR_NBR_TILED"
+#endif
+#ifdef OCVAR_PROF
+           " OCVAR_PROF(env tuning + knock-out switches + cycle counters: NOT a product build)"
+#else
+           " product(no environment tuning, no knock-out switches; OCVAR_TRACE_LAUNCHES only)"
+#endif
+        ;
+}
+
 // OCVAR_TRACE_LAUNCHES=1: wait after every launch and name it on stderr (locating a faulting or hanging kernel)
 static bool trace_launches() {
     static const bool on = std::getenv("OCVAR_TRACE_LAUNCHES") != nullptr;
@@ -283,7 +320,8 @@ static bool trace_launches() {
     } while (0)
 
 static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride, int n_frames,
-                        int grey_in_place, const OcvarMarker* prev, const int* prev_counts, hipStream_t s, int stages) {
+                        int grey_in_place, const OcvarMarker* prev, const int* prev_counts, hipStream_t s, int stages,
+                        bool prev_on_device = false) {
     Workspace& w = c->ws;
     if (!d_bgr || width < 16 || height < 16 || width > w.max_w || height > w.max_h || n_frames < 1 || n_frames > w.max_batch ||
         (size_t)width * height > (size_t)w.max_w * w.max_h || row_stride < 3 * width)
@@ -307,17 +345,19 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     // duration is then the longest walk (~800 one-microsecond steps around a crop) -- such batches hand everything longer
     // than 128 steps to the wave tier, which crosses straight runs 64 pixels at a time (1080p, one frame per call: 3.2 ->
     // 2.5 ms).  Large batches keep the long budget: there the one-lane walks are what fills the machine.
-    w.mid_steps = std::getenv("OCVAR_MID_STEPS") ? std::atoi(std::getenv("OCVAR_MID_STEPS")) : (n_frames <= 8 ? 128 : MID_STEPS);
+    w.mid_steps = tuned(c, OCVAR_TUNE_MID_STEPS, "OCVAR_MID_STEPS", n_frames <= 8 ? 128 : MID_STEPS);
+    if (w.mid_steps < 32) w.mid_steps = 32;
     // Crop tier 2 in two phases saves half of its steps but chains two launches: throughput for batches (+1..2 %), 0.1 ms of
-    // latency for a one-frame call -- which therefore keeps the single launch (env OCVAR_CROP_PHASES overrides).
-    w.crop_phases = std::getenv("OCVAR_CROP_PHASES") ? (std::atoi(std::getenv("OCVAR_CROP_PHASES")) == 1 ? 1 : 2) : (n_frames <= 8 ? 1 : 2);
-    w.mid_blocks = std::getenv("OCVAR_MID_BLOCKS") ? std::atoi(std::getenv("OCVAR_MID_BLOCKS")) : w.max_mid_blocks;
+    // latency for a one-frame call -- which therefore keeps the single launch.
+    w.crop_phases = tuned(c, OCVAR_TUNE_CROP_PHASES, "OCVAR_CROP_PHASES", n_frames <= 8 ? 1 : 2) == 1 ? 1 : 2;
+    w.mid_blocks = tuned(c, OCVAR_TUNE_MID_BLOCKS, "OCVAR_MID_BLOCKS", w.max_mid_blocks);
     if (w.mid_blocks < 1 || w.mid_blocks > w.max_mid_blocks) w.mid_blocks = w.max_mid_blocks;
-    w.long_blocks = std::getenv("OCVAR_LONG_BLOCKS") ? std::atoi(std::getenv("OCVAR_LONG_BLOCKS")) : w.max_long_blocks;
+    w.long_blocks = tuned(c, OCVAR_TUNE_LONG_BLOCKS, "OCVAR_LONG_BLOCKS", w.max_long_blocks);
     if (w.long_blocks < 1 || w.long_blocks > w.max_long_blocks) w.long_blocks = w.max_long_blocks;
     // the fixed grids of the work-queue kernels shrink with the batch: a one-frame call does not launch (and wait out) the
     // thousands of workgroups that keep a 2048-frame batch busy
-    w.short_blocks = std::getenv("OCVAR_SHORT_BLOCKS") ? std::atoi(std::getenv("OCVAR_SHORT_BLOCKS")) : (n_frames >= 128 ? 1024 : (n_frames * 8 < 16 ? 16 : n_frames * 8));
+    w.short_blocks = tuned(c, OCVAR_TUNE_SHORT_BLOCKS, "OCVAR_SHORT_BLOCKS", n_frames >= 128 ? 1024 : (n_frames * 8 < 16 ? 16 : n_frames * 8));
+    if (w.short_blocks < 1 || w.short_blocks > 65535) w.short_blocks = 1024;
     w.crop_blocks = n_frames >= 128 ? 2048 : (n_frames * 16 < 32 ? 32 : n_frames * 16);
     w.frame_strips = (w.sw + MARCH_STRIP - 1) / MARCH_STRIP;
     {   // rows per binarise work unit: even, chunks of equal size.  Every chunk re-reads ~12 halo rows, so chunks are as
@@ -326,7 +366,7 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
         // and three 360-row chunks per 1080p frame were 20 % slower than eight 136-row ones at 256 frames.)
         int chunks = (w.sh + 64) / 128;
         if (chunks < 1) chunks = 1;
-        static const long long min_units = std::getenv("OCVAR_MIN_UNITS") ? std::atoll(std::getenv("OCVAR_MIN_UNITS")) : 65536;
+        const long long min_units = tuned(c, OCVAR_TUNE_MIN_UNITS, "OCVAR_MIN_UNITS", 65536);
         while (chunks > 1 && (long long)w.frame_strips * (chunks / 2) * n_frames >= min_units) chunks /= 2;
         int rows = (w.sh + chunks - 1) / chunks;
         rows = (rows + 7) & ~7;   // whole mask tiles (8 rows) per work unit: binarise.hip writes the mask plane tile by tile
@@ -335,7 +375,11 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     }
     HIP_TRY(c, hipMemsetAsync(w.counters, 0, CNT_COUNT * sizeof(int), s));
     HIP_TRY(c, hipMemsetAsync(w.n_quads_frame, 0, n_frames * sizeof(int), s));
-    if (prev && prev_counts) {
+    if (prev && prev_counts && prev_on_device) {
+        // the previous step's markers never left the device (ocvar_hip_enqueue_tracked: streams of a tracker)
+        HIP_TRY(c, hipMemcpyAsync(w.prev, prev, (size_t)n_frames * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(w.n_prev, prev_counts, n_frames * sizeof(int), hipMemcpyDeviceToDevice, s));
+    } else if (prev && prev_counts) {
         // through the context's page-locked buffers: the device never touches the caller's (pageable, possibly tiny) arrays.
         // (A batch is collected before the next one is enqueued on a context, so the buffers are free again by then.)
         std::memcpy(c->h_prev, prev, (size_t)n_frames * MAXM * sizeof(MarkerRec));
@@ -362,9 +406,10 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     launch_binarise_frames(w, d_bgr, row_stride, frame_stride, grey_in_place, s);
     HIP_TRY(c, gate_leave(c->gate, s));
     TRACE_LAUNCH("binarise_frames", s);
-    // Timing experiments (results are then incomplete or wrong; never set in production):
+    // Timing experiments (results are then incomplete or wrong): compiled into profiling builds only (-DOCVAR_PROF, `make prof`)
     //   OCVAR_ONLY_BINARISE=1        stop after the first kernel (tools/binarise_only.py)
     //   OCVAR_SKIP_CROP_KERNELS=bits knock out kernels of the crop pass: 1 binarise_crops, 2 tier 1, 4 tier 2, 8 tier 3
+#ifdef OCVAR_PROF
     static const bool only_binarise = std::getenv("OCVAR_ONLY_BINARISE") != nullptr;
     static const int skip_crop = std::getenv("OCVAR_SKIP_CROP_KERNELS") ? std::atoi(std::getenv("OCVAR_SKIP_CROP_KERNELS")) : 0;
     if (only_binarise || skip_crop) {
@@ -372,6 +417,10 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
         if (!warned) std::fprintf(stderr, "ocvar_hip: OCVAR_ONLY_BINARISE / OCVAR_SKIP_CROP_KERNELS set -- timing experiment, detection results are NOT valid\n");
         warned = true;
     }
+#else
+    constexpr bool only_binarise = false;
+    constexpr int skip_crop = 0;
+#endif
     if (only_binarise) stages = 0;
     HIP_TRY(c, hop(1, s, f));
     if (stages > 0) {
@@ -455,6 +504,13 @@ extern "C" int ocvar_hip_enqueue(OcvarHip* c, uint8_t* d_bgr, int width, int hei
                         stream ? (hipStream_t)stream : c->stream, 3);
 }
 
+extern "C" int ocvar_hip_enqueue_tracked(OcvarHip* c, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                         int n_frames, int grey_in_place, const OcvarMarker* d_prev, const int* d_prev_counts, void* stream) {
+    if (!c || !d_prev || !d_prev_counts) return OCVAR_E_ARG;
+    return enqueue_impl(c, d_bgr, width, height, row_stride, frame_stride, n_frames, grey_in_place, d_prev, d_prev_counts,
+                        stream ? (hipStream_t)stream : c->stream, 3, true);
+}
+
 extern "C" int ocvar_hip_results_to_device(OcvarHip* c, OcvarMarker* d_markers, int* d_counts, void* stream) {
     return ocvar_hip_results_to_device_ex(c, d_markers, d_counts, MAXM, stream);
 }
@@ -527,20 +583,70 @@ static int reserve_staging(OcvarHip* c, size_t bytes) {
     return OCVAR_OK;
 }
 
+// two page-locked host buffers of at least `bytes` each (the library's own: the only host memory of a frame transfer the copy
+// engines ever see, unless the caller's buffer is page-locked by the caller)
+static int reserve_host_stage(OcvarHip* c, size_t bytes) {
+    if (bytes > c->h_stage_bytes) {
+        for (auto& p : c->h_stage) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+        }
+        c->h_stage_bytes = 0;
+        for (auto& p : c->h_stage) HIP_TRY(c, hipHostMalloc((void**)&p, bytes));
+        c->h_stage_bytes = bytes;
+    }
+    return OCVAR_OK;
+}
+
 static int stage_frames(OcvarHip* c, const uint8_t* h, int height, int row_stride, size_t frame_stride, int n_frames) {
     const size_t bytes = (size_t)(n_frames - 1) * frame_stride + (size_t)height * row_stride;
     int rc = reserve_staging(c, bytes);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpy(c->d_frames, h, bytes, hipMemcpyHostToDevice));
+    if ((rc = reserve_host_stage(c, bytes))) return rc;
+    std::memcpy(c->h_stage[0], h, bytes);
+    HIP_TRY(c, hipMemcpyAsync(c->d_frames, c->h_stage[0], bytes, hipMemcpyHostToDevice, c->stream));
     return OCVAR_OK;
 }
 
-// Frames in host memory.  The caller's buffer is page-locked in place for the duration of the call
-// (hipHostRegister; a buffer the caller registered already is used as it is), all sub-batches' host-to-device copies are
-// queued up front on a copy stream, and each sub-batch is detected as soon as its copy has landed -- so the PCIe
-// transfer of sub-batch k+1.. overlaps the kernels of sub-batch k.  The in-place grey of the reference
-// (opencvar.cpp:624-627) travels back on a third stream.  If the buffer cannot be page-locked the call falls back to
-// one synchronous copy (same results).
+// A host-to-host copy of a sub-batch (hundreds of megabytes at 1080p) by a few threads: one core copies ~10 GB/s, the PCIe
+// link behind it takes 46.
+static void host_copy(uint8_t* dst, const uint8_t* src, size_t n) {
+    constexpr size_t PIECE = (size_t)4 << 20;
+    unsigned nt = (unsigned)std::min<size_t>(8, n / PIECE);
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && nt > hw) nt = hw;
+    if (nt < 2) {
+        std::memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = ((n / nt) + 63) & ~(size_t)63;
+    for (unsigned t = 1; t < nt; t++) {
+        const size_t off = per * t, len = off >= n ? 0 : std::min(per, n - off);
+        if (len) th.emplace_back([=] { std::memcpy(dst + off, src + off, len); });
+    }
+    std::memcpy(dst, src, std::min(per, n));
+    for (auto& t : th) t.join();
+}
+
+// is [p, p + bytes) host memory the CALLER has page-locked (hipHostMalloc / hipHostRegister on their side)?
+static bool caller_pinned(const uint8_t* p, size_t bytes) {
+    hipPointerAttribute_t a{}, b{};
+    const bool ok = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost &&
+                    hipPointerGetAttributes(&b, p + bytes - 1) == hipSuccess && b.type == hipMemoryTypeHost;
+    (void)hipGetLastError();   // "not a HIP pointer" is the ordinary answer for pageable memory
+    return ok;
+}
+
+// Frames in host memory (the reference's caller hands a host IplImage, samples/ARTest.cpp:44-57).
+// The call is cut into sub-batches; while the kernels of sub-batch k run, sub-batch k+1 is copied into one of the context's two
+// page-locked staging buffers (by a few host threads) and from there to the device by the copy engine, and the in-place grey of
+// sub-batch k-1 (opencvar.cpp:624-627) travels back the same way on a third stream.  The library NEVER page-locks the caller's
+// memory (no hipHostRegister / hipHostUnregister: round 2's version did that, and a small heap-resident batch -- which shares
+// its first and last page with whatever malloc put next to it -- ended in a GPU memory fault on a host address; DESIGN.md
+// section 9 lists what that range shared pages with).  A caller that wants the copies straight from its own buffer
+// page-locks it itself (hipHostMalloc, or hipHostRegister for as long as it likes): such a buffer is recognised
+// (hipPointerGetAttributes) and used in place.
 constexpr int HOST_SUB_BATCH = 64;
 
 extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,
@@ -549,52 +655,39 @@ extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int
     if (!c || !h_bgr || n_frames < 1 || height < 1 || row_stride < 1) return OCVAR_E_ARG;
     if (n_frames > 1 && frame_stride < (size_t)height * row_stride) return OCVAR_E_ARG;
     if (!counts || max_per_frame < 0 || (max_per_frame > 0 && !markers)) return OCVAR_E_ARG;
+    if (c->pending) {
+        c->err = "the previous batch of this context has not been collected";
+        return OCVAR_E_ARG;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t frame_bytes = (size_t)height * row_stride;
     const size_t bytes = (size_t)(n_frames - 1) * frame_stride + frame_bytes;
-    int rc = reserve_staging(c, bytes);
+    const int sub = c->ws.max_batch < HOST_SUB_BATCH ? c->ws.max_batch : HOST_SUB_BATCH;
+    const int n_sub = (n_frames + sub - 1) / sub;
+    auto span = [&](int k, size_t* off, int* cnt) {   // sub-batch k: byte offset in the caller's buffer, frames, bytes
+        *cnt = (k + 1) * sub <= n_frames ? sub : n_frames - k * sub;
+        *off = (size_t)k * sub * frame_stride;
+        return (size_t)(*cnt - 1) * frame_stride + frame_bytes;
+    };
+    const size_t span_max = (size_t)((n_frames < sub ? n_frames : sub) - 1) * frame_stride + frame_bytes;
+    const bool direct = caller_pinned(h_bgr, bytes);
+    int rc = reserve_staging(c, 2 * span_max + 256);   // two device slots (256-byte aligned)
     if (rc) return rc;
-
-    // Page-locking the caller's buffer in place pays off (and is only done) for batches of several megabytes; small ones --
-    // a handful of small frames in a heap block that shares its pages with other data -- go through the bounce buffer.
-    bool registered_here = false, pinned = false;
-    if (n_frames > 1 && bytes >= ((size_t)8 << 20)) {
-        const hipError_t e = hipHostRegister(h_bgr, bytes, hipHostRegisterDefault);
-        if (e == hipSuccess) registered_here = pinned = true;
-        else if (e == hipErrorHostMemoryAlreadyRegistered) pinned = true;
-        (void)hipGetLastError();
+    const size_t slot_bytes = (span_max + 255) & ~(size_t)255;
+    if (!direct && (rc = reserve_host_stage(c, span_max))) return rc;
+    if (!c->h2d_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+    if (!c->d2h_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+    while (c->h2d_done.size() < 2) {
+        hipEvent_t ev;
+        HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c->h2d_done.push_back(ev);
     }
-    if (!pinned) {
-        // One frame (the reference's per-frame call, ARTest.cpp:57), or a buffer that cannot be page-locked: the frames go
-        // through the context's own page-locked bounce buffer, so both transfers are plain stream-ordered DMA (a pageable
-        // hipMemcpy is staged by the runtime chunk by chunk and blocks twice).
-        const int sub = c->ws.max_batch;
-        for (int k = 0; k * sub < n_frames; k++) {
-            const int cnt = (k + 1) * sub <= n_frames ? sub : n_frames - k * sub;
-            const size_t off = (size_t)k * sub * frame_stride, len = (size_t)(cnt - 1) * frame_stride + frame_bytes;
-            if (len > c->h_stage_bytes) {
-                if (c->h_stage) (void)hipHostFree(c->h_stage);
-                c->h_stage = nullptr;
-                c->h_stage_bytes = 0;
-                HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, len));
-                c->h_stage_bytes = len;
-            }
-            std::memcpy(c->h_stage, h_bgr + off, len);
-            HIP_TRY(c, hipMemcpyAsync(c->d_frames + off, c->h_stage, len, hipMemcpyHostToDevice, c->stream));
-            rc = enqueue_impl(c, c->d_frames + off, width, height, row_stride, frame_stride, cnt, grey_in_place,
-                              prev ? prev + (size_t)k * sub * MAXM : nullptr, prev_counts ? prev_counts + k * sub : nullptr, c->stream, 3);
-            if (rc) return rc;
-            if (grey_in_place) HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_frames + off, len, hipMemcpyDeviceToHost, c->stream));
-            rc = ocvar_hip_collect(c, markers ? markers + (size_t)k * sub * max_per_frame : nullptr, counts + k * sub, max_per_frame);
-            if (rc) return rc;
-            if (grey_in_place) std::memcpy(h_bgr + off, c->h_stage, len);
-        }
-        return OCVAR_OK;
-    }
-
+    // On any failure: nothing of this call may still be in flight when it returns (the staging buffers are reused by the next)
     auto fail = [&](int code) {
-        (void)hipDeviceSynchronize();
-        if (registered_here) (void)hipHostUnregister(h_bgr);
+        (void)hipStreamSynchronize(c->h2d_stream);
+        (void)hipStreamSynchronize(c->d2h_stream);
+        (void)hipStreamSynchronize(c->stream);
+        c->pending = false;
         return code;
     };
 #define HIP_TRY_HOST(expr)                                            \
@@ -605,43 +698,49 @@ extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int
             return fail(OCVAR_E_HIP);                                 \
         }                                                             \
     } while (0)
-    if (!c->h2d_stream) HIP_TRY_HOST(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
-    if (!c->d2h_stream) HIP_TRY_HOST(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
-    if (!c->computed) HIP_TRY_HOST(hipEventCreateWithFlags(&c->computed, hipEventDisableTiming));
-    const int sub = c->ws.max_batch < HOST_SUB_BATCH ? c->ws.max_batch : HOST_SUB_BATCH;
-    const int n_sub = (n_frames + sub - 1) / sub;
-    while ((int)c->h2d_done.size() < n_sub) {
-        hipEvent_t ev;
-        HIP_TRY_HOST(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        c->h2d_done.push_back(ev);
-    }
-    auto span = [&](int k, size_t* off, int* cnt) {
-        *cnt = (k + 1) * sub <= n_frames ? sub : n_frames - k * sub;
-        *off = (size_t)k * sub * frame_stride;
-        return (size_t)(*cnt - 1) * frame_stride + frame_bytes;
+    // slot k & 1 (host and device) carries sub-batch k
+    auto upload = [&](int k) -> hipError_t {
+        size_t off;
+        int cnt;
+        const size_t len = span(k, &off, &cnt);
+        const uint8_t* src = h_bgr + off;
+        if (!direct) {
+            host_copy(c->h_stage[k & 1], src, len);
+            src = c->h_stage[k & 1];
+        }
+        hipError_t e = hipMemcpyAsync(c->d_frames + (size_t)(k & 1) * slot_bytes, src, len, hipMemcpyHostToDevice, c->h2d_stream);
+        if (e == hipSuccess) e = hipEventRecord(c->h2d_done[k & 1], c->h2d_stream);
+        return e;
     };
+    auto grey_home = [&](int k) -> hipError_t {   // the grey frames of sub-batch k, already on their way, into the caller's buffer
+        const hipError_t e = hipStreamSynchronize(c->d2h_stream);
+        if (e != hipSuccess || direct) return e;
+        size_t off;
+        int cnt;
+        const size_t len = span(k, &off, &cnt);
+        host_copy(h_bgr + off, c->h_stage[k & 1], len);
+        return hipSuccess;
+    };
+    HIP_TRY_HOST(upload(0));
     for (int k = 0; k < n_sub; k++) {
         size_t off;
         int cnt;
         const size_t len = span(k, &off, &cnt);
-        HIP_TRY_HOST(hipMemcpyAsync(c->d_frames + off, h_bgr + off, len, hipMemcpyHostToDevice, c->h2d_stream));
-        HIP_TRY_HOST(hipEventRecord(c->h2d_done[k], c->h2d_stream));
-    }
-    for (int k = 0; k < n_sub; k++) {
-        size_t off;
-        int cnt;
-        const size_t len = span(k, &off, &cnt);
-        HIP_TRY_HOST(hipStreamWaitEvent(c->stream, c->h2d_done[k], 0));
-        rc = ocvar_hip_detect_device(c, c->d_frames + off, width, height, row_stride, frame_stride, cnt, grey_in_place,
-                                     prev ? prev + (size_t)k * sub * MAXM : nullptr, prev_counts ? prev_counts + k * sub : nullptr,
-                                     markers ? markers + (size_t)k * sub * max_per_frame : nullptr, counts + k * sub, max_per_frame);
+        uint8_t* d_slot = c->d_frames + (size_t)(k & 1) * slot_bytes;
+        HIP_TRY_HOST(hipStreamWaitEvent(c->stream, c->h2d_done[k & 1], 0));
+        rc = enqueue_impl(c, d_slot, width, height, row_stride, frame_stride, cnt, grey_in_place,
+                          prev ? prev + (size_t)k * sub * MAXM : nullptr, prev_counts ? prev_counts + k * sub : nullptr, c->stream, 3);
         if (rc) return fail(rc);
-        if (grey_in_place)   // detect_device returned after the sub-batch's kernels finished
-            HIP_TRY_HOST(hipMemcpyAsync(h_bgr + off, c->d_frames + off, len, hipMemcpyDeviceToHost, c->d2h_stream));
+        // while sub-batch k computes: bring sub-batch k-1's grey home, then stage sub-batch k+1 into the slot it leaves
+        if (k > 0 && grey_in_place) HIP_TRY_HOST(grey_home(k - 1));
+        if (k + 1 < n_sub) HIP_TRY_HOST(upload(k + 1));
+        rc = ocvar_hip_collect(c, markers ? markers + (size_t)k * sub * max_per_frame : nullptr, counts + k * sub, max_per_frame);
+        if (rc) return fail(rc);
+        if (grey_in_place)   // (the kernels of sub-batch k have finished: collect waited for them)
+            HIP_TRY_HOST(hipMemcpyAsync(direct ? h_bgr + off : c->h_stage[k & 1], d_slot, len, hipMemcpyDeviceToHost, c->d2h_stream));
     }
-    if (grey_in_place) HIP_TRY_HOST(hipStreamSynchronize(c->d2h_stream));
+    if (grey_in_place) HIP_TRY_HOST(grey_home(n_sub - 1));
 #undef HIP_TRY_HOST
-    if (registered_here) HIP_TRY(c, hipHostUnregister(h_bgr));
     return OCVAR_OK;
 }
 
@@ -698,10 +797,13 @@ extern "C" int ocvar_hip_debug_frame_quads(OcvarHip* c, int frame, int* quads, i
     HIP_TRY(c, hipSetDevice(c->device));
     int n = 0;
     HIP_TRY(c, hipMemcpy(&n, c->ws.n_squares + frame, sizeof(int), hipMemcpyDeviceToHost));
-    std::vector<float> sq((size_t)OCVAR_MAX_QUADS * 8);   // the documented size of `quads`; contexts made for more squares report the first of them
+    // `quads` holds OCVAR_MAX_QUADS quads (the documented size); a context made for fewer or more squares per frame
+    // (ocvar_hip_create_ex) reports what both hold
+    const int lim = c->ws.maxq < OCVAR_MAX_QUADS ? c->ws.maxq : OCVAR_MAX_QUADS;
+    std::vector<float> sq((size_t)lim * 8);
     HIP_TRY(c, hipMemcpy(sq.data(), c->ws.squares + (size_t)frame * c->ws.maxq * 8, sq.size() * sizeof(float), hipMemcpyDeviceToHost));
     *n_quads = n;
-    for (int i = 0; i < n && i < OCVAR_MAX_QUADS; i++)
+    for (int i = 0; i < n && i < lim; i++)
         for (int k = 0; k < 8; k++) quads[8 * i + k] = (int)sq[8 * (size_t)i + k];
     return OCVAR_OK;
 }

@@ -17,6 +17,10 @@ struct OcvarPipe {
     int device = 0, n_ctx = 0, chunk = 0;
     std::vector<OcvarHip*> ctx;
     OcvarGate* gate = nullptr;
+    // tracking state of ocvar_hip_pipe_track_device: every stream's markers of the last step, on the device
+    OcvarMarker* d_state = nullptr;
+    int* d_state_counts = nullptr;
+    long long state_streams = 0;
     std::string err;
 };
 
@@ -24,6 +28,9 @@ extern "C" void ocvar_hip_pipe_destroy(OcvarPipe* p) {
     if (!p) return;
     for (OcvarHip* c : p->ctx) ocvar_hip_destroy(c);
     ocvar_hip_gate_destroy(p->gate);
+    if (p->d_state || p->d_state_counts) (void)hipSetDevice(p->device);
+    if (p->d_state) (void)hipFree(p->d_state);
+    if (p->d_state_counts) (void)hipFree(p->d_state_counts);
     delete p;
 }
 
@@ -71,10 +78,18 @@ extern "C" int ocvar_hip_pipe_set_camera(OcvarPipe* p, const OcvarCamera* cam) {
     return OCVAR_OK;
 }
 
-extern "C" int ocvar_hip_pipe_detect_device(OcvarPipe* p, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
-                                            long long n_frames, int grey_in_place, OcvarMarker* markers, int* counts, int max_per_frame) {
-    if (!p || !d_bgr || n_frames < 1 || !counts || max_per_frame < 0 || (max_per_frame > 0 && !markers)) return OCVAR_E_ARG;
+// The chunk schedule shared by the stateless and the stateful entry point.  tracked: chunk [start, start + cnt) takes its
+// previous markers from the pipe's device-resident state and leaves its results there (stream-ordered behind its kernels;
+// the state rows of different chunks are disjoint).
+static int pipe_run(OcvarPipe* p, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride, long long n_frames,
+                    int grey_in_place, bool tracked, OcvarMarker* markers, int* counts, int max_per_frame) {
     const int K = p->n_ctx;
+    // the contexts bring back as many records per frame as the caller keeps (24 MB per 2048-frame chunk at 64, 3 MB at 8)
+    const int limit = max_per_frame < 1 ? 1 : (max_per_frame > OCVAR_MAX_MARKERS ? OCVAR_MAX_MARKERS : max_per_frame);
+    for (OcvarHip* c : p->ctx) {
+        const int rc = ocvar_hip_set_result_limit(c, limit);
+        if (rc) { p->err = "a context of the pipe still has a batch in flight"; return rc; }
+    }
     struct Flight { long long start = 0; int count = 0; };
     std::vector<Flight> fl((size_t)K);
     long long next = 0;
@@ -84,8 +99,15 @@ extern "C" int ocvar_hip_pipe_detect_device(OcvarPipe* p, uint8_t* d_bgr, int wi
         const int cnt = (int)(left < want ? left : want);
         fl[i].count = 0;
         if (cnt <= 0) return OCVAR_OK;
-        const int rc = ocvar_hip_enqueue(p->ctx[i], d_bgr + (size_t)next * frame_stride, width, height, row_stride, frame_stride, cnt,
-                                         grey_in_place, nullptr, nullptr, nullptr);
+        uint8_t* src = d_bgr + (size_t)next * frame_stride;
+        int rc;
+        if (tracked) {
+            OcvarMarker* st = p->d_state + (size_t)next * OCVAR_MAX_MARKERS;
+            rc = ocvar_hip_enqueue_tracked(p->ctx[i], src, width, height, row_stride, frame_stride, cnt, grey_in_place, st, p->d_state_counts + next, nullptr);
+            if (!rc) rc = ocvar_hip_results_to_device(p->ctx[i], st, p->d_state_counts + next, nullptr);
+        } else {
+            rc = ocvar_hip_enqueue(p->ctx[i], src, width, height, row_stride, frame_stride, cnt, grey_in_place, nullptr, nullptr, nullptr);
+        }
         if (rc) { p->err = ocvar_hip_last_error(p->ctx[i]); return rc; }
         fl[i].start = next;
         fl[i].count = cnt;
@@ -119,4 +141,41 @@ extern "C" int ocvar_hip_pipe_detect_device(OcvarPipe* p, uint8_t* d_bgr, int wi
         }
     }
     return first_err;
+}
+
+extern "C" int ocvar_hip_pipe_detect_device(OcvarPipe* p, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                            long long n_frames, int grey_in_place, OcvarMarker* markers, int* counts, int max_per_frame) {
+    if (!p || !d_bgr || n_frames < 1 || !counts || max_per_frame < 0 || (max_per_frame > 0 && !markers)) return OCVAR_E_ARG;
+    return pipe_run(p, d_bgr, width, height, row_stride, frame_stride, n_frames, grey_in_place, false, markers, counts, max_per_frame);
+}
+
+extern "C" int ocvar_hip_pipe_track_device(OcvarPipe* p, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                           long long n_streams, int grey_in_place, int reset, OcvarMarker* markers, int* counts, int max_per_frame) {
+    if (!p || !d_bgr || n_streams < 1 || !counts || max_per_frame < 0 || (max_per_frame > 0 && !markers)) return OCVAR_E_ARG;
+    if (hipSetDevice(p->device) != hipSuccess) { p->err = "hipSetDevice failed"; return OCVAR_E_HIP; }
+    if (n_streams != p->state_streams) {
+        if (p->d_state) (void)hipFree(p->d_state);
+        if (p->d_state_counts) (void)hipFree(p->d_state_counts);
+        p->d_state = nullptr;
+        p->d_state_counts = nullptr;
+        p->state_streams = 0;
+        if (hipMalloc((void**)&p->d_state, (size_t)n_streams * OCVAR_MAX_MARKERS * sizeof(OcvarMarker)) != hipSuccess ||
+            hipMalloc((void**)&p->d_state_counts, (size_t)n_streams * sizeof(int)) != hipSuccess) {
+            p->err = "out of device memory for the tracking state";
+            return OCVAR_E_HIP;
+        }
+        p->state_streams = n_streams;
+        reset = 1;
+    }
+    // (the contexts' streams do not synchronise with the null stream: the cleared counts must have landed before a chunk reads them)
+    if (reset && (hipMemset(p->d_state_counts, 0, (size_t)n_streams * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) {
+        p->err = "clearing the tracking state failed";
+        return OCVAR_E_HIP;
+    }
+    const int rc = pipe_run(p, d_bgr, width, height, row_stride, frame_stride, n_streams, grey_in_place, true, markers, counts, max_per_frame);
+    if (rc) {   // a failed step leaves no half-updated state behind
+        (void)hipMemset(p->d_state_counts, 0, (size_t)n_streams * sizeof(int));
+        (void)hipDeviceSynchronize();
+    }
+    return rc;
 }

@@ -19,6 +19,9 @@ struct OcvarMulti {
     std::vector<hipStream_t> stream;
     std::vector<uint8_t*> d_block;    // per device: [max_local] x MAXM markers, then [max_local] counts
     std::vector<uint8_t*> d_frames;   // per device: staging of ocvar_multi_detect_host
+    std::vector<OcvarMarker*> d_state;      // per device: tracking state of its streams, [max_local][MAXM] (ocvar_multi_track_*)
+    std::vector<int*> d_state_counts;       // per device: [max_local]
+    std::vector<uint8_t*> h_frames;   // per device: page-locked host staging (the copy engines never see the caller's own memory)
     size_t d_frames_bytes = 0;
     uint8_t* d_all = nullptr;         // root: n blocks
     uint8_t* h_all = nullptr;         // pinned
@@ -63,6 +66,9 @@ extern "C" int ocvar_multi_create(OcvarMulti** out, const int* devices, int n_de
     m->stream.assign(n_devices, nullptr);
     m->d_block.assign(n_devices, nullptr);
     m->d_frames.assign(n_devices, nullptr);
+    m->h_frames.assign(n_devices, nullptr);
+    m->d_state.assign(n_devices, nullptr);
+    m->d_state_counts.assign(n_devices, nullptr);
     for (int d = 0; d < n_devices; d++) {
         const int rc = ocvar_hip_create(&m->ctx[d], m->dev[d], max_width, max_height, max_frames_per_device);
         if (rc != OCVAR_OK) {
@@ -73,6 +79,10 @@ extern "C" int ocvar_multi_create(OcvarMulti** out, const int* devices, int n_de
         M_HIP(m, hipSetDevice(m->dev[d]));
         M_HIP(m, hipStreamCreateWithFlags(&m->stream[d], hipStreamNonBlocking));
         M_HIP(m, hipMalloc((void**)&m->d_block[d], m->block_bytes));
+        M_HIP(m, hipMalloc((void**)&m->d_state[d], marker_bytes(max_frames_per_device)));
+        M_HIP(m, hipMalloc((void**)&m->d_state_counts[d], (size_t)max_frames_per_device * sizeof(int)));
+        M_HIP(m, hipMemset(m->d_state_counts[d], 0, (size_t)max_frames_per_device * sizeof(int)));
+        M_HIP(m, hipDeviceSynchronize());
     }
     M_HIP(m, hipSetDevice(m->dev[0]));
     M_HIP(m, hipMalloc((void**)&m->d_all, m->block_bytes * n_devices));
@@ -94,6 +104,9 @@ extern "C" void ocvar_multi_destroy(OcvarMulti* m) {
         }
         if (m->d_block[d]) (void)hipFree(m->d_block[d]);
         if (m->d_frames[d]) (void)hipFree(m->d_frames[d]);
+        if (m->h_frames[d]) (void)hipHostFree(m->h_frames[d]);
+        if (m->d_state[d]) (void)hipFree(m->d_state[d]);
+        if (m->d_state_counts[d]) (void)hipFree(m->d_state_counts[d]);
         if (m->ctx[d]) ocvar_hip_destroy(m->ctx[d]);
     }
     if (!m->dev.empty()) (void)hipSetDevice(m->dev[0]);
@@ -123,8 +136,10 @@ extern "C" int ocvar_multi_set_camera(OcvarMulti* m, const OcvarCamera* cam) {
     return OCVAR_OK;
 }
 
-extern "C" int ocvar_multi_detect_device(OcvarMulti* m, uint8_t* const* d_bgr, int width, int height, int row_stride, size_t frame_stride,
-                                         const int* n_local, OcvarMarker* markers, int* counts, int max_per_frame) {
+// tracked: every device takes its frames' previous markers from its device-resident state (stream s = local slot s / N of
+// device s mod N) and leaves the new ones there, behind the kernels on its own stream.
+static int multi_run(OcvarMulti* m, uint8_t* const* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                     const int* n_local, bool tracked, OcvarMarker* markers, int* counts, int max_per_frame) {
     if (!m || !d_bgr || !n_local || !counts || max_per_frame < 0 || (max_per_frame > 0 && !markers)) return OCVAR_E_ARG;
     const int N = m->n;
     for (int d = 0; d < N; d++)
@@ -133,34 +148,52 @@ extern "C" int ocvar_multi_detect_device(OcvarMulti* m, uint8_t* const* d_bgr, i
     // counts (ocvar_hip_results_to_device_ex): a caller that keeps 8 markers per frame gathers 1.5 KB per frame instead of 12.
     const int K = max_per_frame < 1 ? 1 : (max_per_frame > MAXM ? MAXM : max_per_frame);
     const size_t block_bytes = marker_bytes(m->max_local, K) + (size_t)m->max_local * sizeof(int);   // <= m->block_bytes (K = MAXM)
+    // A failure after the first enqueue must not leave batches behind: a context refuses a new batch while one is
+    // uncollected, so every device enqueued so far is drained (collected without results) before the error goes back.
+    std::vector<char> enqueued((size_t)N, 0);
+    std::vector<int> scratch_counts((size_t)m->max_local);
+    auto drain = [&](int code, const std::string& what) {
+        m->err = what;
+        for (int d = 0; d < N; d++)
+            if (enqueued[d]) {
+                (void)hipSetDevice(m->dev[d]);
+                (void)ocvar_hip_collect(m->ctx[d], nullptr, scratch_counts.data(), 0);
+            }
+        return code;
+    };
     // every device: detect its share (all kernels of the single-GPU path on the device's own stream), then put the result
     // block into the send buffer behind them
     for (int d = 0; d < N; d++) {
         if (n_local[d] == 0) continue;
-        M_HIP(m, hipSetDevice(m->dev[d]));
-        int rc = ocvar_hip_enqueue(m->ctx[d], d_bgr[d], width, height, row_stride, frame_stride, n_local[d], 0, nullptr, nullptr, m->stream[d]);
-        if (rc) { m->err = ocvar_hip_last_error(m->ctx[d]); return rc; }
+        if (hipSetDevice(m->dev[d]) != hipSuccess) return drain(OCVAR_E_HIP, "hipSetDevice failed");
+        int rc = tracked ? ocvar_hip_enqueue_tracked(m->ctx[d], d_bgr[d], width, height, row_stride, frame_stride, n_local[d], 0,
+                                                     m->d_state[d], m->d_state_counts[d], m->stream[d])
+                         : ocvar_hip_enqueue(m->ctx[d], d_bgr[d], width, height, row_stride, frame_stride, n_local[d], 0, nullptr, nullptr, m->stream[d]);
+        if (rc) return drain(rc, ocvar_hip_last_error(m->ctx[d]));
+        enqueued[d] = 1;
+        if (tracked) {
+            rc = ocvar_hip_results_to_device(m->ctx[d], m->d_state[d], m->d_state_counts[d], m->stream[d]);
+            if (rc) return drain(rc, ocvar_hip_last_error(m->ctx[d]));
+        }
         rc = ocvar_hip_results_to_device_ex(m->ctx[d], reinterpret_cast<OcvarMarker*>(m->d_block[d]),
                                             reinterpret_cast<int*>(m->d_block[d] + marker_bytes(m->max_local, K)), K, m->stream[d]);
-        if (rc) { m->err = ocvar_hip_last_error(m->ctx[d]); return rc; }
+        if (rc) return drain(rc, ocvar_hip_last_error(m->ctx[d]));
     }
     // one gather of the fixed-size blocks to the root (device 0 of the list); a single-thread caller issues all ranks'
     // calls inside one group
-    M_NCCL(m, ncclGroupStart());
-    for (int d = 0; d < N; d++) {
-        const ncclResult_t r = ncclGather(m->d_block[d], d == 0 ? m->d_all : nullptr, block_bytes, ncclUint8, 0, m->comm[d], m->stream[d]);
-        if (r != ncclSuccess) {
-            (void)ncclGroupEnd();
-            m->err = std::string("ncclGather: ") + ncclGetErrorString(r);
-            return OCVAR_E_RCCL;
-        }
+    {
+        ncclResult_t r = ncclGroupStart();
+        for (int d = 0; d < N && r == ncclSuccess; d++)
+            r = ncclGather(m->d_block[d], d == 0 ? m->d_all : nullptr, block_bytes, ncclUint8, 0, m->comm[d], m->stream[d]);
+        const ncclResult_t e = ncclGroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) return drain(OCVAR_E_RCCL, std::string("ncclGather: ") + ncclGetErrorString(r));
     }
-    M_NCCL(m, ncclGroupEnd());
-    M_HIP(m, hipSetDevice(m->dev[0]));
-    M_HIP(m, hipMemcpyAsync(m->h_all, m->d_all, block_bytes * N, hipMemcpyDeviceToHost, m->stream[0]));
+    if (hipSetDevice(m->dev[0]) != hipSuccess ||
+        hipMemcpyAsync(m->h_all, m->d_all, block_bytes * N, hipMemcpyDeviceToHost, m->stream[0]) != hipSuccess)
+        return drain(OCVAR_E_HIP, "copy-out of the gathered blocks failed");
     // collect per device (reports capacity errors of that device's batch), root last: its stream carries the copy-out
     int first_err = OCVAR_OK;
-    std::vector<int> scratch_counts((size_t)m->max_local);
     for (int d = N - 1; d >= 0; d--) {
         if (n_local[d] == 0) continue;
         M_HIP(m, hipSetDevice(m->dev[d]));
@@ -189,13 +222,62 @@ extern "C" int ocvar_multi_detect_device(OcvarMulti* m, uint8_t* const* d_bgr, i
     return OCVAR_OK;
 }
 
+extern "C" int ocvar_multi_detect_device(OcvarMulti* m, uint8_t* const* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                         const int* n_local, OcvarMarker* markers, int* counts, int max_per_frame) {
+    return multi_run(m, d_bgr, width, height, row_stride, frame_stride, n_local, false, markers, counts, max_per_frame);
+}
+
+static int multi_reset_state(OcvarMulti* m) {
+    for (int d = 0; d < m->n; d++) {
+        M_HIP(m, hipSetDevice(m->dev[d]));
+        M_HIP(m, hipMemset(m->d_state_counts[d], 0, (size_t)m->max_local * sizeof(int)));
+        M_HIP(m, hipDeviceSynchronize());   // (the devices' streams do not synchronise with the null stream)
+    }
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_multi_track_device(OcvarMulti* m, uint8_t* const* d_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                        const int* n_local, int reset, OcvarMarker* markers, int* counts, int max_per_frame) {
+    if (!m) return OCVAR_E_ARG;
+    if (reset) {
+        const int rc = multi_reset_state(m);
+        if (rc) return rc;
+    }
+    const int rc = multi_run(m, d_bgr, width, height, row_stride, frame_stride, n_local, true, markers, counts, max_per_frame);
+    if (rc && rc != OCVAR_E_ARG) (void)multi_reset_state(m);   // a failed step leaves no half-updated state behind
+    return rc;
+}
+
+static int multi_stage_host(OcvarMulti* m, const uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride, int n_frames,
+                            std::vector<int>& n_local);
+
 extern "C" int ocvar_multi_detect_host(OcvarMulti* m, const uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,
                                        int n_frames, OcvarMarker* markers, int* counts, int max_per_frame) {
+    std::vector<int> n_local;
+    const int rc = multi_stage_host(m, h_bgr, width, height, row_stride, frame_stride, n_frames, n_local);
+    if (rc) return rc;
+    return multi_run(m, m->d_frames.data(), width, height, row_stride, (size_t)height * row_stride, n_local.data(), false, markers, counts, max_per_frame);
+}
+
+extern "C" int ocvar_multi_track_host(OcvarMulti* m, const uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,
+                                      int n_streams, int reset, OcvarMarker* markers, int* counts, int max_per_frame) {
+    std::vector<int> n_local;
+    const int rc = multi_stage_host(m, h_bgr, width, height, row_stride, frame_stride, n_streams, n_local);
+    if (rc) return rc;
+    return ocvar_multi_track_device(m, m->d_frames.data(), width, height, row_stride, (size_t)height * row_stride, n_local.data(), reset,
+                                    markers, counts, max_per_frame);
+}
+
+// frames of a host batch onto their devices (frame f -> device f mod N, local slot f / N), ordered before the detection on
+// each device's stream
+static int multi_stage_host(OcvarMulti* m, const uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride, int n_frames,
+                            std::vector<int>& n_local_out) {
     if (!m || !h_bgr || n_frames < 1 || n_frames > m->n * m->max_local || height < 1 || row_stride < 3 * width) return OCVAR_E_ARG;
     if (n_frames > 1 && frame_stride < (size_t)height * row_stride) return OCVAR_E_ARG;
     const int N = m->n;
     const size_t fb = (size_t)height * row_stride;
-    std::vector<int> n_local(N, 0);
+    std::vector<int>& n_local = n_local_out;
+    n_local.assign(N, 0);
     for (int f = 0; f < n_frames; f++) n_local[f % N]++;
     if (fb * m->max_local > m->d_frames_bytes) {
         for (int d = 0; d < N; d++) {
@@ -204,13 +286,24 @@ extern "C" int ocvar_multi_detect_host(OcvarMulti* m, const uint8_t* h_bgr, int 
             m->d_frames[d] = nullptr;
             M_HIP(m, hipMalloc((void**)&m->d_frames[d], fb * m->max_local));
         }
+        for (int d = 0; d < N; d++) {
+            M_HIP(m, hipSetDevice(m->dev[d]));
+            if (m->h_frames[d]) (void)hipHostFree(m->h_frames[d]);
+            m->h_frames[d] = nullptr;
+            M_HIP(m, hipHostMalloc((void**)&m->h_frames[d], fb * m->max_local));
+        }
         m->d_frames_bytes = fb * m->max_local;
     }
-    // frame f -> device f mod N, local slot f / N; copies ordered before the detection on the device's stream
-    for (int f = 0; f < n_frames; f++) {
-        const int d = f % N;
+    // frame f -> device f mod N, local slot f / N.  A device's frames are collected in its page-locked staging buffer (the
+    // caller's buffer is ordinary pageable memory: the copy engines only ever see memory this library page-locked itself,
+    // as in ocvar_hip_detect_host) and go over in one copy, ordered before the detection on the device's stream; the
+    // transfer to device d overlaps the host-side collection for device d + 1.
+    for (int d = 0; d < N; d++) {
+        if (n_local[d] == 0) continue;
+        for (int i = 0; i < n_local[d]; i++)
+            std::memcpy(m->h_frames[d] + (size_t)i * fb, h_bgr + (size_t)(d + (size_t)N * i) * frame_stride, fb);
         M_HIP(m, hipSetDevice(m->dev[d]));
-        M_HIP(m, hipMemcpyAsync(m->d_frames[d] + (size_t)(f / N) * fb, h_bgr + (size_t)f * frame_stride, fb, hipMemcpyHostToDevice, m->stream[d]));
+        M_HIP(m, hipMemcpyAsync(m->d_frames[d], m->h_frames[d], fb * n_local[d], hipMemcpyHostToDevice, m->stream[d]));
     }
-    return ocvar_multi_detect_device(m, m->d_frames.data(), width, height, row_stride, fb, n_local.data(), markers, counts, max_per_frame);
+    return OCVAR_OK;
 }

@@ -87,6 +87,38 @@ int main(int argc, char** argv) {
         const int k = cn[f] < OCVAR_MAX_MARKERS ? cn[f] : OCVAR_MAX_MARKERS;
         if (std::memcmp(&mk[(size_t)f * OCVAR_MAX_MARKERS], &ref[(size_t)f * OCVAR_MAX_MARKERS], (size_t)k * sizeof(OcvarMarker)) != 0) mismatches++;
     }
+    // Stateful: the F frames are F video streams; three time steps (the scene of stream s at step t is frame (s + t) % F, so every
+    // stream sees new quads next to tracked ones).  Each stream's markers stay on its device between the calls
+    // (ocvar_multi_track_host); the check is the single-GPU entry point called per step with the previous step's markers handed
+    // back by the host -- the reference's own calling pattern, samples/ARTest.cpp:57 (`markers` persists across frames).
+    int track_mismatches = 0;
+    {
+        std::vector<unsigned char> step_frames(fb * F);
+        std::vector<OcvarMarker> prev((size_t)F * OCVAR_MAX_MARKERS), tk((size_t)F * OCVAR_MAX_MARKERS), tref((size_t)F * OCVAR_MAX_MARKERS);
+        std::vector<int> prev_n(F, 0), tn(F), trefn(F);
+        for (int t = 0; t < 3; t++) {
+            for (int s2 = 0; s2 < F; s2++) std::memcpy(step_frames.data() + fb * s2, frames.data() + fb * ((s2 + (t ? 1 : 0)) % F), fb);
+            rc = ocvar_multi_track_host(m, step_frames.data(), cfg.width, cfg.height, cfg.width * 3, fb, F, t == 0, tk.data(), tn.data(), OCVAR_MAX_MARKERS);
+            if (rc) {
+                std::fprintf(stderr, "ocvar_multi_track_host failed (%d): %s\n", rc, ocvar_multi_last_error(m));
+                return 1;
+            }
+            rc = ocvar_hip_detect_host(one, step_frames.data(), cfg.width, cfg.height, cfg.width * 3, fb, F, 0, t ? prev.data() : nullptr,
+                                       t ? prev_n.data() : nullptr, tref.data(), trefn.data(), OCVAR_MAX_MARKERS);
+            if (rc) {
+                std::fprintf(stderr, "single-GPU tracked reference run failed (%d): %s\n", rc, ocvar_hip_last_error(one));
+                return 1;
+            }
+            for (int f = 0; f < F; f++) {
+                if (tn[f] != trefn[f]) { track_mismatches++; continue; }
+                const int k = tn[f] < OCVAR_MAX_MARKERS ? tn[f] : OCVAR_MAX_MARKERS;
+                if (std::memcmp(&tk[(size_t)f * OCVAR_MAX_MARKERS], &tref[(size_t)f * OCVAR_MAX_MARKERS], (size_t)k * sizeof(OcvarMarker)) != 0) track_mismatches++;
+            }
+            prev = tref;
+            for (int f = 0; f < F; f++) prev_n[f] = trefn[f] < OCVAR_MAX_MARKERS ? trefn[f] : OCVAR_MAX_MARKERS;
+        }
+        mismatches += track_mismatches;
+    }
     ocvar_hip_destroy(one);
     // narrow blocks: a caller that keeps 2 markers per frame gathers 2 records per frame; the counts stay the full counts
     {
@@ -133,8 +165,8 @@ int main(int argc, char** argv) {
     for (int d = 0; d < N; d++)
         if (hipSetDevice(d) == hipSuccess) (void)hipFree(d_bgr[d]);
     ocvar_multi_destroy(m);
-    std::printf("{\"devices\": %d, \"frames\": %d, \"width\": %d, \"height\": %d, \"markers_total\": %lld, \"mismatches_vs_single_gpu\": %d, "
+    std::printf("{\"devices\": %d, \"frames\": %d, \"width\": %d, \"height\": %d, \"markers_total\": %lld, \"mismatches_vs_single_gpu\": %d, \"tracked_steps\": 3, \"tracked_mismatches\": %d, "
                 "\"gather\": \"ncclGather of [frames][%d] CvarMarker + counts to device 0\", \"frames_per_s_device_resident\": %.1f}\n",
-                N, F, cfg.width, cfg.height, total, mismatches, OCVAR_MAX_MARKERS, F / best);
+                N, F, cfg.width, cfg.height, total, mismatches, track_mismatches, OCVAR_MAX_MARKERS, F / best);
     return mismatches ? 1 : 0;
 }

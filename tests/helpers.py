@@ -94,14 +94,29 @@ def synth_lib():
     return _synth
 
 
+_extra_templates = {}
+
+
+def register_template(name, inner):
+    """A template made up at run time (tools/fuzz_parity.py draws random code grids): inner = h x w array of 0/1 cells; the
+    1-cell black frame is added here.  No golden codes exist for it (None): the oracle computes them."""
+    g = np.pad((np.asarray(inner) > 0).astype(np.uint8) * 255, 1)
+    _extra_templates[name] = (np.ascontiguousarray(g), None)
+
+
 def template_pixels():
     """name -> uint8 array (full image incl. the 1-px frame) and expected codes."""
     with open(os.path.join(ROOT, "tests", "golden", "templates.json")) as f:
         d = json.load(f)
-    return {k: (np.array(v["pixels"], dtype=np.uint8), v["codes"]) for k, v in d.items()}
+    out = {k: (np.array(v["pixels"], dtype=np.uint8), v["codes"]) for k, v in d.items()}
+    out.update(_extra_templates)
+    return out
 
 
 TEMPLATE_ORDER = ["2x2-01", "3x3-01", "4x4-01"]
+# synthetic code grids above the shipped sizes (tools/make_templates.py; codes pinned on the reference's compiled acmath.cpp):
+# 5x5, 6x6, 7x7 take the widthStep != width side of the stride quirk, the 8x8 ones fill the long long (two of them negative)
+BIG_TEMPLATES = ["5x5-s1", "6x6-s1", "7x7-s1", "8x8-s1", "8x8-neg", "8x8-corners"]
 
 
 def synth_config(config_id, **over):

@@ -52,7 +52,8 @@ def test_multi_gpu_library_exports_declared_symbols(pkg):
     header = open(os.path.join(H.ROOT, "include", "ocvar_multi.h")).read()
     declared = sorted(set(re.findall(r"\b(ocvar_multi_\w+)\s*\(", header)))
     assert declared == ["ocvar_multi_create", "ocvar_multi_destroy", "ocvar_multi_detect_device", "ocvar_multi_detect_host",
-                        "ocvar_multi_devices", "ocvar_multi_last_error", "ocvar_multi_set_camera", "ocvar_multi_set_templates"]
+                        "ocvar_multi_devices", "ocvar_multi_last_error", "ocvar_multi_set_camera", "ocvar_multi_set_templates",
+                        "ocvar_multi_track_device", "ocvar_multi_track_host"]
     for name in declared:
         assert hasattr(lib, name), name
     import torch

@@ -102,6 +102,87 @@ def test_config3_full_hd_three_templates(oa):
         assert n_c >= 36 and 1 <= len(ref_m) <= 3
 
 
+def test_code_grids_5x5_to_8x8(oa):
+    """Code grids above the shipped 4x4 (the reference's cvarLoadTag defaults to 8x8, opencvar.h:174-175; acArray2DToBit packs
+    64 cells into a long long, acmath.cpp:546-554): 5x5, 6x6, 7x7 read through the widthStep-8 stride quirk, three 8x8 grids
+    -- one ballot lane per cell, all 64 lanes, codes with the sign bit set -- on (tw+2) x (th+2) patches up to 10 x 10, planted
+    in all four rotations.  Templates come from cvarLoadTemplateTag on the PNG fixtures (libopencv-ar.so) and must equal the
+    oracle's; every candidate's bit / orient / corners are compared through check_frame."""
+    import ctypes as C
+    import os
+    import torch
+    names = H.BIG_TEMPLATES
+    cfg = H.synth_config(3, width=1280, height=720, grid_x=4, grid_y=2, rot_mode=0)
+    n = 12
+    det, tpls, cam = make_detector(oa, cfg, names, n)
+    loaded = oa.load_templates([os.path.join(H.ROOT, "tests", "golden", "png", nm + ".png") for nm in names])
+    for a, b in zip(loaded, tpls):
+        assert (a.width, a.height, list(a.code)) == (b.width, b.height, list(b.code))
+    det.set_templates(loaded)
+    frames = np.stack([H.synth_frame(cfg, 40 + f, names)[0] for f in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    markers, counts = det.detect_device(d.data_ptr(), cfg.width, cfg.height, n)
+    seen, negative = {}, 0
+    for f in range(n):
+        check_frame(det, f, frames[f], tpls, cam, markers, counts)
+        for c in det.debug_candidates(f):
+            if c.orient:
+                seen.setdefault(names[c.templateId], set()).add(c.orient)
+                negative += c.bit < 0
+    for nm in ("8x8-s1", "8x8-neg", "8x8-corners"):
+        assert len(seen.get(nm, ())) >= 3, (nm, seen.get(nm))
+    assert set().union(*[seen.get(nm, set()) for nm in ("8x8-s1", "8x8-neg", "8x8-corners")]) == {1, 2, 3, 4}
+    assert negative >= 4
+    for nm in ("5x5-s1", "6x6-s1", "7x7-s1"):
+        assert seen.get(nm) == {1}, (nm, seen.get(nm))
+    # perspective + rotation anywhere + three templates of different sizes at once (mixed tw in one frame's decode loop)
+    cfg2 = H.synth_config(3, width=1000, height=700, grid_x=3, grid_y=2, rot_mode=1, corner_jitter_pct=6)
+    mix = ["8x8-neg", "3x3-01", "6x6-s1", "8x8-corners"]
+    det2, tpls2, cam2 = make_detector(oa, cfg2, mix, 3)
+    fr2 = np.stack([H.synth_frame(cfg2, 7 + f, mix)[0] for f in range(3)])
+    m2, c2 = det2.detect_host(fr2.copy())
+    for f in range(3):
+        check_frame(det2, f, fr2[f], tpls2, cam2, m2, c2)
+
+
+def test_host_entry_with_megabytes_of_frames(oa):
+    """ocvar_hip_detect_host with a batch well above 8 MB (7 x 1280 x 720 x 3 = 19 MB) in an ordinary heap array whose base is
+    not page-aligned, more frames than the context's batch (sub-batches of 3, the last one short), previous markers given
+    (stateful, opencvar.cpp:635-668) and the reference's in-place grey (opencvar.cpp:624-627) coming back: the pipelined host
+    transport (frames staged through the library's own page-locked buffers, copy of sub-batch k+1 overlapping the kernels of
+    sub-batch k) against the oracle, frame by frame.  The caller's arrays are surrounded by guard bytes that must survive."""
+    cfg = H.synth_config(3, width=1280, height=720, grid_x=3, grid_y=2)
+    names = None
+    det, tpls, cam = make_detector(oa, cfg, names, 3)
+    n = 7
+    w, h = cfg.width, cfg.height
+    fb = w * h * 3
+    guard = 64 + 3
+    buf = np.full(2 * guard + n * fb, 0x5A, np.uint8)     # frames start 67 bytes into the block: unaligned in every sense
+    frames = buf[guard:guard + n * fb].reshape(n, h, w, 3)
+    orig = np.stack([H.synth_frame(cfg, 20 + f, names)[0] for f in range(n)])
+    frames[:] = orig
+    assert n * fb >= (8 << 20) and frames.ctypes.data % 4096 != 0
+    # step 1 (stateless) gives the previous markers of step 2
+    m1, c1 = det.detect_host(frames.copy())
+    prev = [[m1[f, k] for k in range(c1[f])] for f in range(n)]
+    ref_prev = [H.oracle_registration(orig[f], tpls, cam)[0] for f in range(n)]
+    markers, counts = det.detect_host(frames, grey_in_place=True, prev=prev)
+    assert (buf[:guard] == 0x5A).all() and (buf[guard + n * fb:] == 0x5A).all()
+    last = n - 1   # the debug hooks see the last sub-batch (frame 6 = its lane 0)
+    for f in range(n):
+        ref_m, _, grey = H.oracle_registration(orig[f], tpls, cam, prev=ref_prev[f])
+        assert np.array_equal(frames[f], grey), f
+        assert counts[f] == len(ref_m), f
+        for k, r in enumerate(ref_m):
+            m = markers[f, k]
+            assert m["templateId"] == r.templateId and m["markerId"] == r.markerId and m["score"] == r.score
+            assert np.abs(m["square"] - np.array(r.square)).max() <= CORNER_TOL
+            g = np.array(r.glMatrix)
+            assert np.abs(m["glMatrix"] - g).max() <= POSE_RTOL * max(1.0, np.abs(g).max())
+    check_frame(det, 0, orig[last], tpls, cam, markers[last:], counts[last:], prev=ref_prev[last])
+
+
 def test_padded_rows_gapped_frames_and_unaligned_base(oa):
     """IplImage.widthStep may exceed 3*width and imageData need not be 4-byte aligned (opencvar.cpp:619 takes any
     8UC3 image): rows padded to 3*W+5 bytes, frames 77 bytes apart, base pointer at an odd address -- the kernel's
@@ -134,8 +215,8 @@ def test_padded_rows_gapped_frames_and_unaligned_base(oa):
 
 
 def test_host_entry_pipelines_sub_batches(oa):
-    """ocvar_hip_detect_host with more frames than the context's batch: the caller's buffer is page-locked in place,
-    copies of later sub-batches overlap detection of earlier ones, grey comes back in place."""
+    """ocvar_hip_detect_host with more frames than the context's batch: sub-batches go through the library's page-locked
+    staging buffers (the copy of the next one overlaps detection of the current one), grey comes back in place."""
     cfg = H.synth_config(2)
     det, tpls, cam = make_detector(oa, cfg, ["2x2-01"], 2)   # sub-batches of 2
     n = 5
@@ -316,28 +397,26 @@ def test_crop_pass_one_and_two_phases_give_the_same_results(oa):
     """The crop pass walks a crop's borders in one launch (batches of <= 8 frames) or in two with exact pruning behind the
     crop's best quad (follow.hip::follow_mid_kernel): both forms, forced on the same textured frames, equal the oracle --
     and with it each other -- candidate for candidate."""
-    import os
     import torch
     cfg = H.synth_config(3, width=800, height=600, grid_x=3, grid_y=2, textured=1, corner_jitter_pct=6, occlude_pct=20)
     n = 10
     det, tpls, cam = make_detector(oa, cfg, None, n)
     frames = np.stack([H.synth_frame(cfg, 100 + f)[0] for f in range(n)])
     d = torch.from_numpy(frames).cuda()
-    old = os.environ.get("OCVAR_CROP_PHASES")
-    try:
-        got = {}
-        for phases in ("1", "2"):
-            os.environ["OCVAR_CROP_PHASES"] = phases
-            markers, counts = det.detect_device(d.data_ptr(), cfg.width, cfg.height, n)
-            for f in range(n):
-                check_frame(det, f, frames[f], tpls, cam, markers, counts)
-            got[phases] = (markers.tobytes(), counts.tobytes())
-        assert got["1"] == got["2"]
-    finally:
-        if old is None:
-            os.environ.pop("OCVAR_CROP_PHASES", None)
-        else:
-            os.environ["OCVAR_CROP_PHASES"] = old
+    got = {}
+    for phases in (1, 2):
+        det.set_tuning(crop_phases=phases)
+        markers, counts = det.detect_device(d.data_ptr(), cfg.width, cfg.height, n)
+        for f in range(n):
+            check_frame(det, f, frames[f], tpls, cam, markers, counts)
+        got[phases] = (markers.tobytes(), counts.tobytes())
+    assert got[1] == got[2]
+    # the other launch parameters of ocvar_hip_set_tuning are result-invariant as well: a short tier-2 budget (everything long
+    # goes to the wave tier), tiny grids, taller binarise chunks
+    det.set_tuning(crop_phases=0, mid_steps=64, mid_blocks=3, long_blocks=2, short_blocks=5, min_units=1)
+    markers, counts = det.detect_device(d.data_ptr(), cfg.width, cfg.height, n)
+    assert (markers.tobytes(), counts.tobytes()) == got[1]
+    assert "product" in oa.build_info() or "OCVAR_PROF" in oa.build_info()
 
 
 def test_round_trip_properties_full_size(oa):

@@ -73,6 +73,12 @@ def test_template_loader_and_camera(host):
         assert [int(c) for c in t.code] == tp[name][1]
     t = H.Template()
     assert host.cvarLoadTemplateTag(C.byref(t), b"/nonexistent.png", 0.01) == 0
+    host.cvarLoadTag.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_double]
+    for name in H.BIG_TEMPLATES:   # cvarLoadTag (opencvar.cpp:311-321) with the header's default 8x8 and the sizes below it
+        codes = tp[name][1]
+        n = tp[name][0].shape[0] - 2
+        host.cvarLoadTag(C.byref(t), codes[0], n, n, 0.5)
+        assert [int(c) for c in t.code] == codes and (t.width, t.height, t.scale) == (n, n, 0.5)
     cam, ref = H.Camera(), H.oracle_camera(1920, 1080)
     assert host.cvarReadCamera(None, C.byref(cam)) == 1
     host.cvarCameraScale(C.byref(cam), 1920, 1080)
@@ -117,6 +123,47 @@ CAMERA_XML = """<?xml version="1.0"?>
     -1.25e-01 2.5e-01 0. -3.0e-04 -1.0e-01</data></distCoeffs>
 </opencv_storage>
 """
+
+
+def test_png_reader_colour_types_and_filters(host):
+    """cvarLoadTemplateTag (opencvar.cpp:284-309: cvLoadImage(GRAYSCALE) -> inner ROI -> threshold 100 -> flip -> code) on
+    the PNG fixtures of tests/golden/png (tools/make_templates.py): 8-bit grey written by PIL, and colour types 0 / 2 (the
+    reference's own 2x2 template is an RGB file) / 3 (palette) / 4 (grey + alpha) / 6 (RGBA), each with every row filter
+    (None, Sub, Up, Average, Paeth) forced by the fixture writer and two IDAT chunks.  Every file gives the codes the
+    reference's compiled acmath.cpp gives for its grid (tests/golden/templates.json)."""
+    host.cvarLoadTemplateTag.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    tp = H.template_pixels()
+    png_dir = os.path.join(H.ROOT, "tests", "golden", "png")
+    index = json.load(open(os.path.join(png_dir, "index.json")))
+    seen = set()
+    for fn, name in sorted(index.items()):
+        t = H.Template()
+        assert host.cvarLoadTemplateTag(C.byref(t), os.path.join(png_dir, fn).encode(), 0.01) == 1, fn
+        assert [int(c) for c in t.code] == tp[name][1], fn
+        assert (t.width, t.height) == (tp[name][0].shape[1] - 2, tp[name][0].shape[0] - 2), fn
+        m = re.match(r".*-c(\d)-f(\d)\.png$", fn)
+        if m:
+            seen.add((int(m.group(1)), int(m.group(2))))
+    assert seen == {(c, f) for c in (0, 2, 3, 4, 6) for f in range(5)}
+    # damaged files are refused (return 0, opencvar.cpp:286-288), never half-read
+    good = open(os.path.join(png_dir, "4x4-01-c6-f4.png"), "rb").read()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for label, data in (("truncated", good[:len(good) // 2]), ("not-a-png", b"P5 4 4 255 " + bytes(16)), ("empty", b"")):
+            p = os.path.join(d, label + ".png")
+            open(p, "wb").write(data)
+            assert host.cvarLoadTemplateTag(C.byref(H.Template()), p.encode(), 0.01) == 0, label
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/template/2x2-01.png"), reason="reference tree not present (build container only)")
+def test_reference_template_files_give_appendix_c_codes(host):
+    """The reference's own three template PNGs (the 2x2 is an RGB file), read where they lie: SURVEY Appendix C's codes."""
+    host.cvarLoadTemplateTag.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    expect = {"2x2-01": [0x8, 0x2, 0x1, 0x4], "3x3-01": [0x174, 0x117, 0x5d, 0x1d1], "4x4-01": [0xdeed, 0x96ff, 0xb77b, 0xff69]}
+    for name, codes in expect.items():
+        t = H.Template()
+        assert host.cvarLoadTemplateTag(C.byref(t), f"/root/reference/template/{name}.png".encode(), 0.01) == 1
+        assert [int(c) for c in t.code] == codes, name
 
 
 @pytest.mark.parametrize("text,ext", [(CAMERA_YAML, "yml"), (CAMERA_XML, "xml")])

@@ -88,11 +88,42 @@ def test_acmath_against_compiled_reference():
 
 
 def test_template_codes_golden():
+    """cvarLoadTemplateTag's arithmetic (opencvar.cpp:284-321) on the pixel grids: the three shipped templates (SURVEY
+    Appendix C) and the synthetic 5x5 .. 8x8 grids, whose codes were computed by the reference's compiled acmath.cpp
+    (tools/make_templates.py) -- 64-cell codes incl. negative ones, and the stride quirk with widthStep 8 for widths 5-7."""
     tp = H.template_pixels()
-    tpls = H.oracle_templates()
-    for t, name in zip(tpls, H.TEMPLATE_ORDER):
+    names = H.TEMPLATE_ORDER + H.BIG_TEMPLATES
+    tpls = H.oracle_templates(names)
+    for t, name in zip(tpls, names):
         assert [int(c) for c in t.code] == tp[name][1], name
-        assert t.width == tp[name][0].shape[1] - 2
+        assert t.width == tp[name][0].shape[1] - 2 and t.height == tp[name][0].shape[0] - 2
+    assert tp["8x8-neg"][1][0] < 0 and all(c < 0 for c in tp["8x8-corners"][1])
+
+
+def test_registration_reads_code_grids_up_to_8x8():
+    """The readout of opencvar.cpp:718-738 on (tw+2) x (th+2) patches up to 10 x 10: planted 8x8 markers decode in all four
+    rotations (widthStep == width: no quirk), negative codes included; 5x5 .. 7x7 read through the widthStep-8 quirk."""
+    cfg = H.synth_config(3, width=1280, height=720, grid_x=4, grid_y=2, rot_mode=0)
+    names = H.BIG_TEMPLATES
+    tp = H.oracle_templates(names)
+    cam = H.oracle_camera(cfg.width, cfg.height)
+    seen = {}
+    negative = 0
+    for f in range(16):
+        bgr, truth = H.synth_frame(cfg, 40 + f, names)
+        markers, cands, _ = H.oracle_registration(bgr, tp, cam)
+        assert len(cands) % len(names) == 0
+        for c in cands:
+            if c.orient:
+                seen.setdefault(names[c.templateId], set()).add(c.orient)
+                negative += c.bit < 0
+    for n in ("8x8-s1", "8x8-neg", "8x8-corners"):
+        assert seen.get(n) == {1, 2, 3, 4}, (n, seen.get(n))
+    assert negative >= 4
+    # widths 5-7: the code is read with stride w from rows 8 bytes apart, so only the upright pose reads back a template code
+    # (as SURVEY B.6 records for the shipped 3x3)
+    for n in ("5x5-s1", "6x6-s1", "7x7-s1"):
+        assert seen.get(n) == {1}, (n, seen.get(n))
 
 
 def test_binarise_is_edge_detector():

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on an MI355X: many synthetic scenes (sizes incl. odd ones, clean/textured backgrounds,
-marker sizes, rotations, perspective jitter, occlusion, 1..3 templates, post-processing noise/blur/contrast) through
+marker sizes, rotations, perspective jitter, occlusion, 1..4 templates (shipped 2x2/3x3/4x4, the pinned 5x5..8x8 grids, random
+grids of any size up to 8x8), post-processing noise/blur/contrast) through
 the HIP path and the oracle, compared with the same bars as tests/test_gpu_parity.py (grey plane, binary image, quads,
 decoded candidates bit-exact; markers exact / pose 1e-4).  Not part of the default test run (minutes of CPU oracle time).
 
@@ -22,6 +23,13 @@ frames_checked = markers_seen = cands_seen = 0
 for s in range(n_scenes):
     w, h = sizes[int(rng.integers(len(sizes)))]
     names = [H.TEMPLATE_ORDER[i] for i in sorted(rng.choice(3, size=int(rng.integers(1, 4)), replace=False))]
+    if s % 2:   # every other scene: code grids up to 8x8 (opencvar.h:174-175) -- the pinned synthetic ones and freshly drawn grids
+        pool = list(H.BIG_TEMPLATES)
+        for k in range(2):
+            n = int(rng.integers(2, 9))
+            H.register_template(f"rnd{s}-{k}", rng.integers(0, 2, (n, n)))
+            pool.append(f"rnd{s}-{k}")
+        names = names[:1] + [pool[i] for i in rng.choice(len(pool), size=int(rng.integers(1, 4)), replace=False)]
     side_min = int(rng.integers(40, 120))
     cell = max(side_min + 60, 140)
     gx, gy = max(1, min(6, w // (cell + 40))), max(1, min(4, h // (cell + 40)))
@@ -45,9 +53,7 @@ for s in range(n_scenes):
     frames = np.ascontiguousarray(np.stack(frames))
     det, tpls, cam = T.make_detector(oa, cfg, names, nb)
     # the crop pass's two forms (follow.hip::follow_mid_kernel): the batch-size default, one launch, two launches with pruning
-    os.environ.pop("OCVAR_CROP_PHASES", None)
-    if s % 3:
-        os.environ["OCVAR_CROP_PHASES"] = str(s % 3)
+    det.set_tuning(crop_phases=s % 3)   # 0: the default for the batch size
     if s % 4 == 3:     # stateful: every lane is a video stream, the scene drifts a few pixels per step (opencvar.cpp:635-668)
         from opencv_ar_amd.tracking import StreamTracker
         tracker = StreamTracker(det, nb)
