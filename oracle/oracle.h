@@ -69,6 +69,11 @@ int orc_find_contours(const uint8_t* bin, int w, int h, int* pts, int max_pts, i
 double orc_arc_length_closed(const int* pts, int n);
 /* Douglas-Peucker as cvApproxPoly(CV_POLY_APPROX_DP) on a closed int contour; returns output count. */
 int orc_approx_poly(const int* pts, int n, double eps, int* out);
+/* Which OpenCV release's cvApproxPoly the oracle restates (process-wide; orc_contours.cpp): 0 = <= 2.4.3 legacy integer routine,
+ * float accuracy (default, the parity definition); 1 = 2.4.4+ approxPolyDP_<int>, double accuracy; 2 = 1 + the inner-product
+ * clean-up condition of later releases.  Only tools/approx_variants.py switches it. */
+void orc_set_approx_variant(int v);
+int orc_get_approx_variant(void);
 double orc_contour_area(const int* pts, int n);
 int orc_is_convex(const int* pts, int n);
 

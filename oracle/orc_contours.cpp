@@ -147,7 +147,126 @@ extern "C" double orc_arc_length_closed(const int* pts, int n) {
     return perimeter;
 }
 
+// ---- which cvApproxPoly?  (parity is unpinned here: no OpenCV in the image; the variants size the uncertainty) ------------------
+// The reference says "OpenCV 2.3 or newer" (README.md:18-19) and calls cvApproxPoly(CV_POLY_APPROX_DP) (opencvar.cpp:190-192).
+//   variant 0 (default; what the HIP path reproduces): the legacy C routine icvApproxPolyDP_32s of OpenCV <= 2.4.3 -- the
+//             accuracy arrives as FLOAT, integer distances, `(float)max_dist <= eps` in the seeding loop.
+//   variant 1: approxPolyDP_<int> of OpenCV 2.4.4+ (cvApproxPoly became a wrapper of the templated C++ routine): the accuracy
+//             stays DOUBLE, distances are computed in double, no float cast anywhere.
+//   variant 2: the same with the extra clean-up condition `successive_inner_product >= 0` of later 2.4.x / 3.x releases.
+// All from recollection of those sources.  tools/approx_variants.py counts over >= 10 k synthetic frames how often a variant
+// changes a contour's vertices, a frame's quads, or a final marker (DESIGN.md section 5 has the numbers).
+static int g_approx_variant = 0;
+extern "C" void orc_set_approx_variant(int v) { g_approx_variant = v < 0 || v > 2 ? 0 : v; }
+extern "C" int orc_get_approx_variant(void) { return g_approx_variant; }
+
+static int approx_poly_double(const int* src, int count, double eps, int* dst, bool inner_product) {
+    struct Slice { int start, end; };
+    if (count == 0) return 0;
+    eps *= eps;
+    std::vector<Slice> stack;
+    Slice slice = {0, 0}, right_slice = {0, 0};
+    int new_count = 0;
+    int sx = 0, sy = 0, ex = 0, ey = 0, px = 0, py = 0;
+    bool le_eps = false;
+    int pos = 0;
+    // READ_PT(pt, pos): pt = src[pos]; if (++pos >= count) pos = 0
+#define RD(X, Y) do { X = src[2 * pos]; Y = src[2 * pos + 1]; if (++pos >= count) pos = 0; } while (0)
+    right_slice.start = 0;
+    for (int i = 0; i < 3; i++) {
+        double max_dist = 0;
+        pos = (pos + right_slice.start) % count;
+        RD(sx, sy);
+        for (int j = 1; j < count; j++) {
+            RD(px, py);
+            const double dx = px - sx, dy = py - sy;
+            const double dist = dx * dx + dy * dy;
+            if (dist > max_dist) {
+                max_dist = dist;
+                right_slice.start = j;
+            }
+        }
+        le_eps = max_dist <= eps;
+    }
+    if (!le_eps) {
+        right_slice.end = slice.start = pos % count;
+        slice.end = right_slice.start = (right_slice.start + slice.start) % count;
+        stack.push_back(right_slice);
+        stack.push_back(slice);
+    } else {
+        dst[0] = sx;
+        dst[1] = sy;
+        new_count = 1;
+    }
+    while (!stack.empty()) {
+        slice = stack.back();
+        stack.pop_back();
+        ex = src[2 * slice.end];
+        ey = src[2 * slice.end + 1];
+        pos = slice.start;
+        RD(sx, sy);
+        if (pos != slice.end) {
+            const double dx = ex - sx, dy = ey - sy;
+            double max_dist = 0;
+            while (pos != slice.end) {
+                RD(px, py);
+                const double dist = std::fabs((py - sy) * dx - (px - sx) * dy);
+                if (dist > max_dist) {
+                    max_dist = dist;
+                    right_slice.start = (pos + count - 1) % count;
+                }
+            }
+            le_eps = max_dist * max_dist <= eps * (dx * dx + dy * dy);
+        } else {
+            le_eps = true;
+            sx = src[2 * slice.start];
+            sy = src[2 * slice.start + 1];
+        }
+        if (le_eps) {
+            dst[2 * new_count] = sx;
+            dst[2 * new_count + 1] = sy;
+            new_count++;
+        } else {
+            right_slice.end = slice.end;
+            slice.end = right_slice.start;
+            stack.push_back(right_slice);
+            stack.push_back(slice);
+        }
+    }
+#undef RD
+    count = new_count;
+    if (count == 0) return 0;
+    int r = count - 1;
+#define RDD(X, Y) do { X = dst[2 * r]; Y = dst[2 * r + 1]; if (++r >= count) r = 0; } while (0)
+    RDD(sx, sy);
+    int wpos = r;
+    RDD(px, py);
+    for (int i = 0; i < count && new_count > 2; i++) {
+        RDD(ex, ey);
+        const double dx = ex - sx, dy = ey - sy;
+        const double dist = std::fabs((px - sx) * dy - (py - sy) * dx);
+        const double sip = (double)(px - sx) * (ex - px) + (double)(py - sy) * (ey - py);
+        if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && (!inner_product || sip >= 0)) {
+            new_count--;
+            dst[2 * wpos] = sx = ex;
+            dst[2 * wpos + 1] = sy = ey;
+            if (++wpos >= count) wpos = 0;
+            RDD(px, py);
+            i++;
+            continue;
+        }
+        dst[2 * wpos] = sx = px;
+        dst[2 * wpos + 1] = sy = py;
+        if (++wpos >= count) wpos = 0;
+        px = ex;
+        py = ey;
+    }
+#undef RDD
+    return new_count;
+}
+
 extern "C" int orc_approx_poly(const int* src, int count, double parameter, int* dst) {
+    if (g_approx_variant) return approx_poly_double(src, count, parameter, dst, g_approx_variant == 2);
     // icvApproxPolyDP_32s, closed contour; eps is passed as float by cvApproxPoly.
     struct Slice { int start, end; };
     float eps = (float)parameter;

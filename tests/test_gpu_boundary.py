@@ -142,6 +142,9 @@ def test_multi_gpu_helper_gathers_over_rccl():
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["devices"] >= 1 and rec["frames"] == 6 * rec["devices"] and rec["mismatches_vs_single_gpu"] == 0
     assert rec["markers_total"] >= rec["frames"]
+    # stateful: streams sharded over the devices, their markers kept on their device between three steps
+    # (ocvar_multi_track_host) == per-step single-GPU calls with the markers handed back by the host
+    assert rec["tracked_steps"] == 3 and rec["tracked_mismatches"] == 0
 
 
 def test_rccl_gather_of_result_blocks_world1():
@@ -234,9 +237,9 @@ def test_registration_of_a_frame_with_hundreds_of_squares():
 
 def test_small_frames_in_heap_blocks_never_reach_the_device_directly():
     """Small batches of small frames live in malloc'ed heap blocks that share their pages with other data; a randomised
-    sweep once faulted the GPU on such a host address while it was page-locked in place.  Batches below 8 MB and the
-    previous-marker arrays now travel through the context's own page-locked buffers: many odd-sized stateful calls,
-    results against the oracle."""
+    sweep once faulted the GPU on such a host address while the block was page-locked in place (round 2).  The library no
+    longer page-locks caller memory at all: frames of every size and the previous-marker arrays travel through the
+    context's own page-locked buffers.  Many odd-sized stateful calls, results against the oracle."""
     import opencv_ar_amd as oa
     from opencv_ar_amd.tracking import StreamTracker
     rng = np.random.default_rng(9)
@@ -327,6 +330,79 @@ def test_pipe_of_contexts_equals_one_context():
         m2, c2 = pipe.detect_device(d.data_ptr(), cfg.width, cfg.height, n, max_per_frame=8)
         assert c1.tobytes() == c2.tobytes() and c1.min() >= 1
         assert m1.tobytes() == m2.tobytes()
+
+
+def test_pipe_tracks_streams_with_state_on_the_device():
+    """ocvar_hip_pipe_track_device: 11 video streams, chunks of 4 going round 2 contexts, 3 time steps; every stream's markers
+    of the previous step stay in device memory between the calls (ocvar_hip_enqueue_tracked).  Against the oracle run
+    sequentially per stream (opencvar.cpp:635-668), and against one context that is handed the previous markers from the
+    host, record for record."""
+    import torch
+    import opencv_ar_amd as oa
+    cfg = H.synth_config(2)
+    names = ["2x2-01"]
+    ns = 11
+    tpls_o, cam_o = H.oracle_templates(names), H.oracle_camera(cfg.width, cfg.height)
+    tpls = [oa.Template.from_buffer_copy(bytes(t)) for t in tpls_o]
+    cam = oa.Camera.from_buffer_copy(bytes(cam_o))
+    pipe = oa.Pipe(cfg.width, cfg.height, chunk_frames=4, n_contexts=2, gate_width=1)
+    pipe.set_templates(tpls)
+    pipe.set_camera(cam)
+    det = oa.Detector(cfg.width, cfg.height, max_batch=ns)
+    det.set_templates(tpls)
+    det.set_camera(cam)
+    seq = [[3 + s, 4 + s, 4 + s] for s in range(ns)]   # synthetic frame index of stream s at step t (a repeated frame tracks onto itself)
+    ref_prev = [None] * ns
+    host_prev = None
+    for t in range(3):
+        frames = np.stack([H.synth_frame(cfg, seq[s][t], names)[0] for s in range(ns)])
+        d = torch.from_numpy(frames).cuda()
+        torch.cuda.synchronize()
+        markers, counts = pipe.track_device(d.data_ptr(), cfg.width, cfg.height, ns, reset=(t == 0))
+        m1, c1 = det.detect_device(d.data_ptr(), cfg.width, cfg.height, ns, prev=host_prev)
+        assert counts.tobytes() == c1.tobytes()
+        for s in range(ns):
+            assert markers[s, :counts[s]].tobytes() == m1[s, :c1[s]].tobytes()
+            ref_m, _, _ = H.oracle_registration(frames[s], tpls_o, cam_o, prev=ref_prev[s])
+            assert counts[s] == len(ref_m)
+            for k, r in enumerate(ref_m):
+                assert markers[s, k]["markerId"] == r.markerId and markers[s, k]["templateId"] == r.templateId and markers[s, k]["score"] == r.score
+                assert np.abs(markers[s, k]["square"] - np.array(r.square)).max() <= 0.5
+                g = np.array(r.glMatrix)
+                assert np.abs(markers[s, k]["glMatrix"] - g).max() <= 1e-4 * max(1.0, np.abs(g).max())
+            ref_prev[s] = ref_m
+        host_prev = [[m1[s, k] for k in range(c1[s])] for s in range(ns)]
+    assert max(len(r) for r in ref_prev) >= 2   # tracked + new markers were carried
+    # a reset forgets the streams: the next step equals a stateless call
+    markers, counts = pipe.track_device(d.data_ptr(), cfg.width, cfg.height, ns, reset=True)
+    m0, c0 = det.detect_device(d.data_ptr(), cfg.width, cfg.height, ns)
+    assert counts.tobytes() == c0.tobytes() and all(markers[s, :c0[s]].tobytes() == m0[s, :c0[s]].tobytes() for s in range(ns))
+
+
+def test_host_entry_uses_a_buffer_the_caller_page_locked_in_place():
+    """A caller that wants PCIe copies straight out of its own buffer page-locks it itself (hipHostMalloc: torch's pinned
+    memory); ocvar_hip_detect_host recognises such a buffer and skips its staging copies.  Same results and in-place grey as the
+    staged path on ordinary memory."""
+    import torch
+    import opencv_ar_amd as oa
+    cfg = H.synth_config(2)
+    names = ["2x2-01"]
+    n = 7
+    tpls = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, x + ".png") for x in names])
+    cam = oa.default_camera(cfg.width, cfg.height)
+    frames = np.stack([H.synth_frame(cfg, 50 + f, names)[0] for f in range(n)])
+    frames[..., 2] = (frames[..., 2].astype(np.int32) * 7 // 8).astype(np.uint8)   # R != G = B: greying changes the bytes
+    det = oa.Detector(cfg.width, cfg.height, max_batch=3)
+    det.set_templates(tpls)
+    det.set_camera(cam)
+    plain = frames.copy()
+    m1, c1 = det.detect_host(plain, grey_in_place=True)
+    pinned_t = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True)
+    pinned = pinned_t.numpy()
+    pinned[:] = frames
+    m2, c2 = det.detect_host(pinned, grey_in_place=True)
+    assert c1.tobytes() == c2.tobytes() and m1.tobytes() == m2.tobytes() and c1.min() >= 1
+    assert np.array_equal(plain, pinned) and not np.array_equal(plain, frames)   # both greyed in place
 
 
 def test_ready_and_result_limit():
