@@ -16,6 +16,12 @@ import os
 import sys
 import time
 
+# Multi-process GPU work on this pool (one rank per GPU, RCCL over xGMI): the host driver only supports dmabuf IPC; without
+# this RCCL's cross-process buffer registration fails with "hipIpcGetMemHandle: invalid argument".  The ROCm runtime reads
+# it when it initialises, i.e. it must be in the environment before the first HIP call of the process (torch is imported
+# below).  The image exports it already; a caller's shell that dropped it gets it back here.  (One-rank runs do not need it.)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -302,6 +308,7 @@ def main():
             "config": {"workload": f"configs[{args.config - 1}]: {W}x{Hh}, {cfg.grid_x * cfg.grid_y} markers/frame, templates "
                                    f"{'2x2' if names else '2x2/3x3/4x4 x 4 rotations'}, batch {B} frames/GPU/step "
                                    f"({uniq} distinct) in {NS} stream(s)" + (f", at most {args.gate} binarise kernels at once" if gate is not None else "") + ", stateless", "frames_per_step_per_gpu": B, "streams": NS,
+                       "library": oa.build_info(),
                        "parallelism": f"frame-sharded x{world}" + ((f", RCCL gather of CvarMarker arrays ({GATHER_K} records per frame + counts)" if backend == "nccl" else f", {backend} rehearsal of the gather (ranks share devices)") if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -84,4 +84,11 @@ int cvarTrack(CvPoint2D32f pt1[4], CvPoint2D32f pt2[4]);
 int cvarArMultRegistration(IplImage* image, vector<CvarMarker>* markers, vector<CvarTemplate> templates,
                            CvarCamera* camera);
 
+/* EXTENSION (not in the reference's header; nothing in the reference calls it).  The sequences cvarFindSquares returns live in
+ * the caller's CvMemStorage in the reference, i.e. until cvClearMemStorage / cvReleaseMemStorage (opencvar.cpp:168).  This
+ * library is built without OpenCV, so it keeps them itself, keyed by the storage pointer that was passed (NULL is a key too):
+ * a storage's sequences stay valid until this call, or until that same storage has collected more than 4096 of them (then
+ * its oldest goes).  Call it where the reference's caller clears or releases the storage. */
+AC_DLL void cvarReleaseSquares(CvMemStorage* storage);
+
 }  // extern "C"

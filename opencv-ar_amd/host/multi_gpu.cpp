@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,6 +55,10 @@ size_t marker_bytes(int frames, int per_frame = MAXM) { return (size_t)frames * 
 extern "C" int ocvar_multi_create(OcvarMulti** out, const int* devices, int n_devices, int max_width, int max_height, int max_frames_per_device) {
     if (!out || n_devices < 1 || max_frames_per_device < 1) return OCVAR_E_ARG;
     *out = nullptr;
+    // RCCL between GPUs needs dmabuf IPC on hosts whose driver has no legacy IPC (this pool): HSA_ENABLE_IPC_MODE_LEGACY=0,
+    // read by the ROCm runtime when it initialises.  Set here if the caller's environment lacks it -- effective only when
+    // this is the process's first HIP call; a process that touched HIP earlier must export it itself.
+    (void)setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < n_devices) return OCVAR_E_NO_DEVICE;
     OcvarMulti* m = new OcvarMulti();

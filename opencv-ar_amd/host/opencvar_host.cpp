@@ -22,6 +22,7 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <map>
 #include <string>
 
 static_assert(sizeof(CvarCamera) == sizeof(OcvarCamera) && sizeof(CvarCamera) == 248, "CvarCamera layout");
@@ -70,7 +71,14 @@ std::mutex g_mu;
 OcvarHip* g_ctx = nullptr;
 int g_w = 0, g_h = 0;
 int g_maxq = OCVAR_MAX_QUADS;   // squares per frame the current context has room for (grows when a frame needs more)
-std::deque<std::unique_ptr<OwnedSeq>> g_seqs;  // keeps returned sequences alive (the reference uses CvMemStorage)
+// Sequences handed out by cvarFindSquares, per CvMemStorage* the caller passed.  In the reference a sequence lives in the
+// caller's storage until that storage is cleared or released (opencvar.cpp:168, 621-630, 803-804).  OpenCV is not part of
+// this build, so the storage is an opaque key here: a key's sequences stay alive until cvarReleaseSquares(key) -- the
+// counterpart of cvClearMemStorage / cvReleaseMemStorage for this library -- or until the key has collected more than
+// SEQS_PER_STORAGE of them, when the oldest goes (one registration of the reference creates 1 + quads x templates sequences in
+// its storage: hundreds at most).  Different storages never evict each other's sequences.
+constexpr size_t SEQS_PER_STORAGE = 4096;
+std::map<const void*, std::deque<std::unique_ptr<OwnedSeq>>> g_seqs;
 std::vector<CvarTemplate> g_templates;        // what the context currently holds: unchanged arguments are not uploaded again
 CvarCamera g_camera;
 bool g_have_camera = false;
@@ -403,7 +411,12 @@ CvRect cvarSquare2Rect(CvPoint2D32f pt[4]) {
 
 int cvarTrack(CvPoint2D32f pt1[4], CvPoint2D32f pt2[4]) { return ocvar::track_square(&pt1[0].x, &pt2[0].x); }
 
-CvSeq* cvarFindSquares(IplImage* img, CvMemStorage* /*storage*/) {
+void cvarReleaseSquares(CvMemStorage* storage) {   // extension (not in the reference's header): see g_seqs
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_seqs.erase(storage);
+}
+
+CvSeq* cvarFindSquares(IplImage* img, CvMemStorage* storage) {
     std::lock_guard<std::mutex> lk(g_mu);
     std::unique_ptr<OwnedSeq> seq(new OwnedSeq());
     if (image_ok(img)) {
@@ -448,9 +461,11 @@ CvSeq* cvarFindSquares(IplImage* img, CvMemStorage* /*storage*/) {
         }
     }
     seq->seal();
-    g_seqs.push_back(std::move(seq));
-    if (g_seqs.size() > 256) g_seqs.pop_front();
-    return &g_seqs.back()->seq;
+    seq->seq.storage = storage;
+    auto& mine = g_seqs[storage];
+    mine.push_back(std::move(seq));
+    if (mine.size() > SEQS_PER_STORAGE) mine.pop_front();
+    return &mine.back()->seq;
 }
 
 int cvarGetSquare(CvSeq* squares, CvPoint2D32f* points) {

@@ -114,6 +114,29 @@ def test_debug_square_api_through_the_reference_boundary(host):
             assert img_arr[y, x].tolist() == [0, 255, 0]
 
 
+def test_find_squares_sequences_live_as_long_as_their_storage(host):
+    """In the reference the returned CvSeq lives in the caller's CvMemStorage (opencvar.cpp:168).  Here a storage pointer is a
+    key: hundreds of later calls with OTHER storages (the old 256-sequence ring would have freed it) leave a sequence intact;
+    cvarReleaseSquares(key) -- this library's stand-in for cvClearMemStorage -- ends its life."""
+    cfg = H.synth_config(2)
+    frame, _ = H.synth_frame(cfg, 3, ["2x2-01"])
+    grey = np.ascontiguousarray(np.repeat(frame[..., :1], 3, axis=2))
+    ref = H.oracle_find_squares(np.ascontiguousarray(grey[..., 0]))
+    img = ipl(grey)
+    key_a, key_b = C.c_void_p(0x1000), C.c_void_p(0x2000)   # opaque keys: never dereferenced by the library
+    seq = host.cvarFindSquares(C.byref(img), key_a)
+    assert seq.contents.storage == key_a.value
+    small = ipl(np.ascontiguousarray(grey[:64, :64]))
+    for _ in range(300):
+        host.cvarFindSquares(C.byref(small), key_b)
+    assert np.array_equal(seq_points(seq), ref)
+    host.cvarReleaseSquares.argtypes = [C.c_void_p]
+    host.cvarReleaseSquares.restype = None
+    host.cvarReleaseSquares(key_b)
+    assert np.array_equal(seq_points(seq), ref)
+    host.cvarReleaseSquares(key_a)
+
+
 def test_find_squares_on_a_colour_image_uses_bgr2gray_weights(host):
     cfg = H.synth_config(2)
     frame, _ = H.synth_frame(cfg, 1, ["2x2-01"])
