@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--gate", type=int, default=2, help="at most this many binarise kernels of the contexts run at once (ocvar_hip_gate_create; 0: no gate)")
     ap.add_argument("--unique", type=int, default=256, help="distinct synthetic frames per GPU (tiled to the batch on the device)")
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config id (3 = headline)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                    help="result-invariant launch parameter for every context (ocvar_hip_set_tuning: crop_phases, mid_steps, mid_blocks, "
+                         "long_blocks, short_blocks, min_units); experiments only -- the default run sets none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-frame-per-call latency leg (child process)")
     ap.add_argument("--no-check", action="store_true", help="skip the result check before the warm-up (profile runs: keeps every launch of a kernel full-size)")
@@ -156,6 +159,8 @@ def main():
         det.set_camera(camera)
         if gate is not None:
             det.set_gate(gate)
+        if args.tune:
+            det.set_tuning(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune})
         det.set_result_limit(8)   # what collect(8) takes: 3 MB instead of 24 MB of marker records per 2048-frame launch
         dets.append(det)
         streams.append(torch.cuda.Stream())
@@ -308,7 +313,7 @@ def main():
             "config": {"workload": f"configs[{args.config - 1}]: {W}x{Hh}, {cfg.grid_x * cfg.grid_y} markers/frame, templates "
                                    f"{'2x2' if names else '2x2/3x3/4x4 x 4 rotations'}, batch {B} frames/GPU/step "
                                    f"({uniq} distinct) in {NS} stream(s)" + (f", at most {args.gate} binarise kernels at once" if gate is not None else "") + ", stateless", "frames_per_step_per_gpu": B, "streams": NS,
-                       "library": oa.build_info(),
+                       "library": oa.build_info(), "tuning": args.tune or "defaults",
                        "parallelism": f"frame-sharded x{world}" + ((f", RCCL gather of CvarMarker arrays ({GATHER_K} records per frame + counts)" if backend == "nccl" else f", {backend} rehearsal of the gather (ranks share devices)") if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,

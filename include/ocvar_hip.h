@@ -124,7 +124,11 @@ int ocvar_hip_set_result_limit(OcvarHip* ctx, int max_per_frame);
 enum { OCVAR_TUNE_CROP_PHASES = 1, /* crop-pass tier 2 in 1 launch or 2 (exact pruning behind the crop's best quad) */
        OCVAR_TUNE_MID_STEPS = 2,   /* step budget of follower tier 2 before a border goes to the wave tier (>= 32) */
        OCVAR_TUNE_MID_BLOCKS = 3, OCVAR_TUNE_LONG_BLOCKS = 4, OCVAR_TUNE_SHORT_BLOCKS = 5, /* grids of tiers 2, 3, 1 */
-       OCVAR_TUNE_MIN_UNITS = 6 }; /* binarise work units per launch below which row chunks are not made taller */
+       OCVAR_TUNE_MIN_UNITS = 6,   /* binarise work units per launch below which row chunks are not made taller */
+       OCVAR_TUNE_HP_MASK = 7 };   /* kernels launched on the context's high-priority stream, one bit per launch: 1 tier 1
+                                    * (frames), 2 tier 2, 4 tier 3, 8 order/crops, 16 tier 1 (crops), 32 tier 2, 64 tier 3,
+                                    * 128 decode, 256 dedupe+pose; ocvar_hip_set_tuning(ctx, OCVAR_TUNE_HP_MASK, m) sets mask m
+                                    * (0 = none), there is no "back to default" for this knob short of a new context */
 int ocvar_hip_set_tuning(OcvarHip* ctx, int knob, int value);
 /* How the library was built: "... product(...)" or "... OCVAR_PROF(...)" -- bench.py prints it with its number. */
 const char* ocvar_hip_build_info(void);

@@ -36,7 +36,7 @@ struct OcvarHip {
     int tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ocvar_hip_set_tuning: 0 = default
     Workspace ws{};
     hipStream_t stream = nullptr;
-    hipStream_t hp_stream = nullptr;   // high-priority stream of the latency-bound kernels (env OCVAR_SPLIT_STREAMS=1; default off)
+    hipStream_t hp_stream = nullptr;   // high-priority stream for the kernels OCVAR_TUNE_HP_MASK names (created on first use)
     hipStream_t last_stream = nullptr;
     hipEvent_t ev[13]{};   // 12 intervals: see ocvar_hip_stage_ms
     std::vector<void*> allocs;
@@ -100,16 +100,6 @@ extern "C" int ocvar_hip_create_ex(OcvarHip** out, int device, int max_width, in
     c->device = device;
     HIP_TRY(c, hipSetDevice(device));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-#ifdef OCVAR_PROF
-    {   // (an experiment kept for profiling builds: measured with 4 contexts, no gain -- see enqueue_impl)
-        const char* e = std::getenv("OCVAR_SPLIT_STREAMS");
-        if (e && std::atoi(e) != 0) {
-            int lo = 0, hi = 0;
-            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi: numerically lowest = greatest priority
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->hp_stream, hipStreamNonBlocking, hi));
-        }
-    }
-#endif
     for (auto& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
     Workspace& w = c->ws;
     w.max_w = max_width;
@@ -275,8 +265,10 @@ extern "C" int ocvar_hip_set_camera(OcvarHip* c, const OcvarCamera* cam) {
 // A result-invariant launch parameter: the context's own setting (ocvar_hip_set_tuning), else the default.  Profiling builds
 // (-DOCVAR_PROF) also listen to the environment variable of the same purpose; the product library reads no tuning from the
 // environment, so a benchmark number cannot depend on the caller's shell.
+constexpr int HP_MASK_DEFAULT = 0;
+
 static long long tuned(const OcvarHip* c, int knob, const char* env_name, long long dflt) {
-    if (knob > 0 && knob < 8 && c->tune[knob] > 0) return c->tune[knob];
+    if (knob > 0 && knob < 8 && c->tune[knob] > 0) return knob == OCVAR_TUNE_HP_MASK ? c->tune[knob] - 1 : c->tune[knob];
 #ifdef OCVAR_PROF
     if (const char* e = std::getenv(env_name)) return std::atoll(e);
 #else
@@ -286,8 +278,8 @@ static long long tuned(const OcvarHip* c, int knob, const char* env_name, long l
 }
 
 extern "C" int ocvar_hip_set_tuning(OcvarHip* c, int knob, int value) {
-    if (!c || knob < 1 || knob > 6 || value < 0 || c->pending) return OCVAR_E_ARG;
-    c->tune[knob] = value;
+    if (!c || knob < 1 || knob > 7 || value < 0 || c->pending) return OCVAR_E_ARG;
+    c->tune[knob] = knob == OCVAR_TUNE_HP_MASK ? value + 1 : value;   // (0 is a meaningful mask: stored off by one, 0 = default)
     return OCVAR_OK;
 }
 
@@ -389,16 +381,27 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     } else {
         HIP_TRY(c, hipMemsetAsync(w.n_prev, 0, n_frames * sizeof(int), s));
     }
-    // Optional (OCVAR_SPLIT_STREAMS=1): the two streaming kernels (VALU-bound, tens of thousands of workgroups) stay on the
-    // caller's stream, the border followers and the tail -- latency-bound, a few hundred long-lived workgroups -- go to
-    // this context's high-priority stream, so that with several contexts in flight their workgroups are placed ahead of
-    // the queued workgroups of another context's binarise kernel.  Measured with 4 contexts: the followers' in-region
-    // durations halve, binarise's grows by as much (138 k vs 142 k frames/s) -- off by default.  The events that time
-    // the stages also order the two streams.
-    hipStream_t f = c->hp_stream ? c->hp_stream : s;
-    auto hop = [&](int k, hipStream_t from, hipStream_t to) -> hipError_t {   // ev[k] on `from`; `to` continues after it
-        hipError_t e = hipEventRecord(c->ev[k], from);
-        if (e == hipSuccess && from != to) e = hipStreamWaitEvent(to, c->ev[k], 0);
+    // Which kernels run on the context's high-priority stream (OCVAR_TUNE_HP_MASK, one bit per launch after the first
+    // binarise kernel: 1 tier 1 (frames), 2 tier 2, 4 tier 3, 8 order/crops, 16 tier 1 (crops), 32 tier 2, 64 tier 3, 128 decode,
+    // 256 dedupe+pose).  With several contexts in flight a binarise kernel of another context has tens of thousands of
+    // 80-register workgroups queued, and every slot a finished one frees is refilled from that queue at once: a kernel with a
+    // larger footprint -- decode and dedupe+pose: 256 / 64 threads at 128 registers -- finds room only by accident and takes 6 ms
+    // in-region for 0.3 ms of work, at the end of its context's chain.  On a high-priority queue its workgroups are placed
+    // first.  (All followers on the high-priority stream -- round 2's OCVAR_SPLIT_STREAMS -- halved their in-region durations and
+    // lengthened binarise's by as much; the mask chooses kernel by kernel.)  The events that time the stages also order the
+    // streams.
+    const int hp_mask = (int)tuned(c, OCVAR_TUNE_HP_MASK, "OCVAR_HP_MASK", HP_MASK_DEFAULT) & 0x1ff;
+    if (hp_mask && !c->hp_stream) {
+        int lo = 0, hi = 0;
+        HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi: numerically lowest = greatest priority
+        HIP_TRY(c, hipStreamCreateWithPriority(&c->hp_stream, hipStreamNonBlocking, hi));
+    }
+    hipStream_t cur = s;   // the stream the chain is on
+    auto stage = [&](int k, int bit) -> hipError_t {   // timing event k at the end of the previous stage; the next one runs where its bit says
+        hipStream_t to = (bit >= 0 && ((hp_mask >> bit) & 1)) ? c->hp_stream : s;
+        hipError_t e = hipEventRecord(c->ev[k], cur);
+        if (e == hipSuccess && to != cur) e = hipStreamWaitEvent(to, c->ev[k], 0);
+        cur = to;
         return e;
     };
     HIP_TRY(c, gate_enter(c->gate, s));   // (before the first timing event: a wait at the gate is not binarise time)
@@ -422,44 +425,46 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     constexpr int skip_crop = 0;
 #endif
     if (only_binarise) stages = 0;
-    HIP_TRY(c, hop(1, s, f));
     if (stages > 0) {
-    launch_follow_frames(w, f);
-    TRACE_LAUNCH("follow tier 1 (frames)", f);
-    HIP_TRY(c, hipEventRecord(c->ev[2], f));
-    launch_follow_mid_frames(w, f);
-    TRACE_LAUNCH("follow tier 2 (frames)", f);
-    HIP_TRY(c, hipEventRecord(c->ev[3], f));
-    launch_follow_long_frames(w, f);
-    TRACE_LAUNCH("follow tier 3 (frames)", f);
-    HIP_TRY(c, hipEventRecord(c->ev[4], f));
-    launch_order_and_crops(w, f);
-    TRACE_LAUNCH("order_and_crops", f);
+        HIP_TRY(c, stage(1, 0));
+        launch_follow_frames(w, cur);
+        TRACE_LAUNCH("follow tier 1 (frames)", cur);
+        HIP_TRY(c, stage(2, 1));
+        launch_follow_mid_frames(w, cur);
+        TRACE_LAUNCH("follow tier 2 (frames)", cur);
+        HIP_TRY(c, stage(3, 2));
+        launch_follow_long_frames(w, cur);
+        TRACE_LAUNCH("follow tier 3 (frames)", cur);
+        HIP_TRY(c, stage(4, 3));
+        launch_order_and_crops(w, cur);
+        TRACE_LAUNCH("order_and_crops", cur);
     } else {
-        for (int k = 2; k < 5; k++) HIP_TRY(c, hipEventRecord(c->ev[k], f));
+        for (int k = 1; k < 5; k++) HIP_TRY(c, hipEventRecord(c->ev[k], s));
     }
     if (stages > 2) {
-        HIP_TRY(c, gate_enter(c->gate, s));   // (a wait here is booked under the order_crops interval)
-        HIP_TRY(c, hop(5, f, s));
+        // (the gate wait is enqueued on s before s is made to wait for the order kernel: a wait here is booked under the
+        // order_crops interval)
+        HIP_TRY(c, gate_enter(c->gate, s));
+        HIP_TRY(c, stage(5, -1));
         if (!(skip_crop & 1)) launch_binarise_crops(w, s);
         HIP_TRY(c, gate_leave(c->gate, s));
         TRACE_LAUNCH("binarise_crops", s);
-        HIP_TRY(c, hop(6, s, f));
-        if (!(skip_crop & 2)) launch_follow_crops(w, f);
-        TRACE_LAUNCH("follow tier 1 (crops)", f);
-        HIP_TRY(c, hipEventRecord(c->ev[7], f));
-        if (!(skip_crop & 4)) launch_follow_mid_crops(w, f);
-        TRACE_LAUNCH("follow tier 2 (crops)", f);
-        HIP_TRY(c, hipEventRecord(c->ev[8], f));
-        if (!(skip_crop & 8)) launch_follow_long_crops(w, f);
-        TRACE_LAUNCH("follow tier 3 (crops)", f);
-        HIP_TRY(c, hipEventRecord(c->ev[9], f));
-        launch_decode(w, f);
-        TRACE_LAUNCH("decode", f);
-        HIP_TRY(c, hipEventRecord(c->ev[10], f));
-        launch_finalise(w, f);
-        TRACE_LAUNCH("finalise", f);
-        HIP_TRY(c, hop(11, f, s));
+        HIP_TRY(c, stage(6, 4));
+        if (!(skip_crop & 2)) launch_follow_crops(w, cur);
+        TRACE_LAUNCH("follow tier 1 (crops)", cur);
+        HIP_TRY(c, stage(7, 5));
+        if (!(skip_crop & 4)) launch_follow_mid_crops(w, cur);
+        TRACE_LAUNCH("follow tier 2 (crops)", cur);
+        HIP_TRY(c, stage(8, 6));
+        if (!(skip_crop & 8)) launch_follow_long_crops(w, cur);
+        TRACE_LAUNCH("follow tier 3 (crops)", cur);
+        HIP_TRY(c, stage(9, 7));
+        launch_decode(w, cur);
+        TRACE_LAUNCH("decode", cur);
+        HIP_TRY(c, stage(10, 8));
+        launch_finalise(w, cur);
+        TRACE_LAUNCH("finalise", cur);
+        HIP_TRY(c, stage(11, -1));
         HIP_TRY(c, hipMemcpyAsync(c->h_counts, w.n_markers, n_frames * sizeof(int), hipMemcpyDeviceToHost, s));
         if (c->result_limit >= MAXM)
             HIP_TRY(c, hipMemcpyAsync(c->h_markers, w.markers, (size_t)n_frames * MAXM * sizeof(MarkerRec), hipMemcpyDeviceToHost, s));
@@ -467,7 +472,7 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
             HIP_TRY(c, hipMemcpy2DAsync(c->h_markers, (size_t)MAXM * sizeof(MarkerRec), w.markers, (size_t)MAXM * sizeof(MarkerRec),
                                         (size_t)c->result_limit * sizeof(MarkerRec), (size_t)n_frames, hipMemcpyDeviceToHost, s));
     } else {
-        HIP_TRY(c, hop(5, f, s));
+        HIP_TRY(c, stage(5, -1));
         for (int k = 6; k < 12; k++) HIP_TRY(c, hipEventRecord(c->ev[k], s));
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, w.counters, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));

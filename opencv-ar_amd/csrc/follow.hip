@@ -621,6 +621,100 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
     if (CROP) append(2, o_n2);
 }
 
+// ---- the follower's step from a table (tier 2) ------------------------------------------------------------------------------
+// trace_core.h::flat_step_t spends ~70 vector instructions per step: the rotate / count-trailing-zeros / rotate-back that turn
+// (arrival direction, neighbour mask) into (exit direction, neighbours passed on the way), two table extractions for the
+// direction's dx and dy, the scan position y * ns + x carried next to x and y, the tiled address from scratch, and a chain of
+// selects.  The step is rebuilt around three ideas:
+//  * the mask only matters through t = the number of zero neighbours examined before the next border pixel (a byte replicate,
+//    a funnel shift and a find-first-bit), and everything the step decides is a function of (first examined direction, t): 64
+//    states, ONE lookup in a 256-byte LDS table: entry = (dx + 1) | (dy + 1) << 16 | next first direction << 5 | exit
+//    direction << 10 | passed-E << 30 | passed-W << 31.  (A table over (direction, mask) itself -- 8 KB per workgroup -- saved
+//    four more instructions and cost a workgroup of occupancy next to the binarise kernels: slower.)
+//  * the position is the packed point x | y << 16 itself (what is parked and stored anyway): one add3 moves it, and because y
+//    is the major half, packed points compare like scan positions y * ns + x -- the "a position of this border before its
+//    start" tests and the closing test need no scan position at all (passed-W / passed-E sit in the sign bits: an AND with the
+//    signed distance to the start position decides).
+//  * a walk that ends is never stepped again, so nothing is guarded.
+// ~42 vector instructions per step instead of ~70; same states, same points, same status as flat_step_t, step for step
+// (tests/test_gpu_parity.py compares every quad and candidate with the oracle; tools/fuzz_parity.py sweeps).
+constexpr unsigned LW_EXIT = 0x1c00u;        // exit direction << 10
+constexpr unsigned LW_DELTA = 0x00030003u;   // (dx + 1) | (dy + 1) << 16
+
+__device__ __forceinline__ unsigned lean_table_entry(unsigned idx) {   // idx = t << 3 | first examined direction
+    const unsigned from = idx & 7u, t = idx >> 3;
+    const unsigned e = (from + t) & 7u;
+    const unsigned dx = (unsigned)(step_dx((int)e) + 1), dy = (unsigned)(step_dy((int)e) + 1);
+    // the t neighbours from, from + 1, ... were examined and found zero: was W (direction 4) / E (direction 0) among them?
+    const unsigned pw = ((12u - from) & 7u) < t, pe = ((8u - from) & 7u) < t;
+    return dx | (dy << 16) | (((e + 5u) & 7u) << 5) | (e << 10) | (pe << 30) | (pw << 31);
+}
+
+struct LeanWalk {
+    unsigned xy;        // current pixel, x | y << 16
+    unsigned m;         // its neighbour mask
+    unsigned from;      // first direction examined from it = arrival direction + 1 (mod 8)
+    unsigned pe;        // previous exit direction << 10: a corner point wherever the exit direction changes
+    unsigned xy0, xy1;  // the border's first pixel and the pixel the closing step comes from
+    unsigned cxy;       // the start's scan position as a packed point
+    int npts, step, status;   // status: -1 while running, then a TraceStatus
+};
+
+__device__ __forceinline__ void lean_begin(LeanWalk& w, const uint8_t* nbr, int ns, int cpos, int is_hole) {
+    const int i0 = cpos - is_hole;
+    const int x = i0 % ns, y = i0 / ns;
+    w.xy = w.xy0 = (unsigned)x | ((unsigned)y << 16);
+    w.cxy = w.xy0 + (unsigned)is_hole;   // (a hole's start position is the pixel east of its first pixel, same row)
+    w.npts = 0;
+    w.step = 0;
+    w.status = -1;
+    w.xy1 = 0;
+    w.pe = 0;
+    w.from = 0;
+    w.m = nbr[nbr_addr(x, y, ns)];
+    if (w.m == 0) {   // single-pixel domain (only reachable for outer borders)
+        w.status = TRACE_SINGLE;
+        w.npts = 1;
+        return;
+    }
+    const int s = first_cw(w.m, (is_hole ? 0 : 4) - 1);   // direction of the border's last pixel seen from its first
+    w.xy1 = w.xy0 + (unsigned)(step_dx(s) + 65536 * step_dy(s));
+    w.pe = (unsigned)(s ^ 4) << 10;                        // prev_s = s ^ 4
+    w.from = (unsigned)(s + 1) & 7u;
+}
+
+// One step of a running walk.  tab: the 64-entry table in LDS; base / nt / last: the walk's plane (its first byte, tiles per
+// tile row = ns >> 4, its last byte offset); park(xy): the caller parks the pixel being left (every step; only a corner point
+// advances npts afterwards).
+template <class Park>
+__device__ __forceinline__ void lean_step(LeanWalk& w, const unsigned* tab, const uint8_t* base, unsigned nt, unsigned last, Park&& park) {
+    const unsigned mm = __builtin_amdgcn_perm(w.m, w.m, 0u);                       // the mask in all four bytes
+    const unsigned t = (unsigned)__builtin_ctz(__builtin_amdgcn_alignbit(mm, mm, w.from));   // zero neighbours before the next border pixel
+    const unsigned ent = tab[(t << 3) + w.from];
+    const int d = (int)(w.xy - w.cxy);                             // < 0: this pixel's west side precedes the start
+    const unsigned nf = ((ent << 1) & (unsigned)(d + 1)) | (ent & (unsigned)d);   // sign: an earlier position of this border was passed
+    const unsigned nxy = w.xy + (ent & LW_DELTA) - 0x10001u;
+    const bool closes = (nxy == w.xy0) & (w.xy == w.xy1);
+    const unsigned e = ent & LW_EXIT;
+    const bool emit = e != w.pe;
+    // tiled address of the next pixel (hd.h::nbr_addr on the packed point).  A consistent plane never sends a walk outside
+    // itself; should one be inconsistent the offset is clamped (no access outside the plane), the walk runs into its budget and
+    // the wave tier, which checks every coordinate, reports it.
+    unsigned off = __umul24(nxy >> 19, nt) + ((nxy >> 4) & 0xfffu);
+    off = (off << 7) | (nxy & 15u);
+    off |= (nxy >> 12) & 0x70u;
+    off = off < last ? off : last;
+    const unsigned m4 = base[off];
+    park(w.xy);
+    w.npts += emit ? 1 : 0;
+    w.status = (int)nf < 0 ? (int)TRACE_NOT_FIRST : closes ? (int)TRACE_OK : m4 == 0u ? (int)TRACE_OVERRUN : -1;
+    w.step += 1;
+    w.xy = nxy;
+    w.pe = e;
+    w.from = (ent >> 5) & 7u;
+    w.m = m4;
+}
+
 // ---- Tier 2: one lane per surviving border, 64 independent walks per wave, lanes refilled as they finish -------------
 // A walk is a chain of dependent byte loads, so a wave's time is its longest walk; with one batch of 64 starts per wave
 // most lanes would sit idle behind the longest border (a crop holds a ~900-step border next to 100-step ones).  Here a
@@ -647,6 +741,9 @@ template <bool CROP>
 __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws, int phase) {
     __shared__ WaveScratch scratch[4];
     __shared__ unsigned parked[4][64 * POINT_ROW];
+    __shared__ unsigned step_tab[64];
+    if (threadIdx.x < 64u) step_tab[threadIdx.x] = lean_table_entry(threadIdx.x);
+    __syncthreads();
     const StartCand* cands = CROP ? ws.mid_crop : ws.mid_frame;
     StartCand* longs = CROP ? ws.long_crop : ws.long_frame;
     int n = ws.counters[CROP ? CNT_MID_C : CNT_MID_F];
@@ -671,8 +768,11 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws, int phase
     StartCand c;
     c.roi = 0; c.pos = 0; c.is_hole = 0;
     PlaneRef pl = plane_of<CROP>(ws, 0);
-    FlatWalk w;
+    LeanWalk w;
+    w.xy = w.m = w.from = w.pe = w.xy0 = w.xy1 = w.cxy = 0u;
+    w.npts = w.step = 0;
     w.status = TRACE_NOT_FIRST;
+    unsigned pl_nt = 1u, pl_last = 0u;   // tiles per tile row and last byte offset of the lane's plane
     // every round hands out at least one start or retires at least one walk after <= budget / MID_BLOCK rounds of stepping
     long long guard = ((long long)n + 64) * (budget / MID_BLOCK + 5) + 64;
     PROF_DECL();
@@ -709,7 +809,9 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws, int phase
                     }
                     pl = plane_of<CROP>(ws, c.roi);
                     if (take && c.pos > 0 && c.pos < pl.plane) {
-                        flat_begin(w, pl.nbr, pl.ns, c.pos, c.is_hole);
+                        lean_begin(w, pl.nbr, pl.ns, c.pos, c.is_hole);
+                        pl_nt = (unsigned)(pl.ns >> 4);
+                        pl_last = (unsigned)nbr_plane_bytes(pl.ns, pl.sh) - 1u;
                         have = true;
                         flushed = 0;
                     }
@@ -725,11 +827,11 @@ __global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws, int phase
             PROF_ADD(4, 1);
             PROF_ADD(5, __popcll(__ballot(running)));
             if (running)
-                flat_step_t<false>(w, pl.nbr, pl.ns, pl.plane, c.pos, budget, [&](bool, int x, int y) {
+                lean_step(w, step_tab, pl.nbr, pl_nt, pl_last, [&](unsigned xy) {
                     // every step writes its pixel at the running count; only a corner point advances the count, so a step
                     // without one is overwritten by the next (beyond the slab's capacity: the row's spare slot)
                     const int slot = w.npts - flushed;
-                    my_row[slot < MID_BLOCK ? slot : MID_BLOCK] = (unsigned)x | ((unsigned)y << 16);
+                    my_row[slot < MID_BLOCK ? slot : MID_BLOCK] = xy;
                 });
         }
         // the step budget is checked here, once per block, instead of in every step (a walk may overshoot it by up to
