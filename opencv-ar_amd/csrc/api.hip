@@ -153,6 +153,7 @@ extern "C" int ocvar_hip_create_ex(OcvarHip** out, int device, int max_width, in
     if ((rc = dev_alloc(c, &w.reserve, B * MAXM))) return rc;
     if ((rc = dev_alloc(c, &w.n_reserve, B))) return rc;
     if ((rc = dev_alloc(c, &w.markers, B * MAXM))) return rc;
+    if ((rc = dev_alloc(c, &w.pose_jobs, B * MAXM))) return rc;
     if ((rc = dev_alloc(c, &w.n_markers, B))) return rc;
     if ((rc = dev_alloc(c, &w.templates, (size_t)MAXT))) return rc;
     if ((rc = dev_alloc(c, &w.camera, (size_t)1))) return rc;
@@ -342,7 +343,11 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     // Crop tier 2 in two phases saves half of its steps but chains two launches: throughput for batches (+1..2 %), 0.1 ms of
     // latency for a one-frame call -- which therefore keeps the single launch.
     w.crop_phases = tuned(c, OCVAR_TUNE_CROP_PHASES, "OCVAR_CROP_PHASES", n_frames <= 8 ? 1 : 2) == 1 ? 1 : 2;
-    w.mid_blocks = tuned(c, OCVAR_TUNE_MID_BLOCKS, "OCVAR_MID_BLOCKS", w.max_mid_blocks);
+    // Tier 2's grid: alone on the GPU a context wants every lane it can get (its duration is a chain of dependent loads; 1024
+    // workgroups: 2.8 ms for the crop pass of 2048 frames, 256: 4.6 ms).  A context that shares the GPU with others (it has a
+    // gate) takes a quarter: tier 2's 110-register waves then leave room for the other contexts' binarise waves (4 contexts:
+    // 171 -> 176 k frames/s; 128 or 512 workgroups: 171 / 173 k).
+    w.mid_blocks = tuned(c, OCVAR_TUNE_MID_BLOCKS, "OCVAR_MID_BLOCKS", c->gate ? std::max(32, w.max_mid_blocks / 4) : w.max_mid_blocks);
     if (w.mid_blocks < 1 || w.mid_blocks > w.max_mid_blocks) w.mid_blocks = w.max_mid_blocks;
     w.long_blocks = tuned(c, OCVAR_TUNE_LONG_BLOCKS, "OCVAR_LONG_BLOCKS", w.max_long_blocks);
     if (w.long_blocks < 1 || w.long_blocks > w.max_long_blocks) w.long_blocks = w.max_long_blocks;

@@ -5,8 +5,9 @@
 // square finder on the crop once per template with an identical result; here the crop pass ran
 // once and every template reads the same crop quad.  Templates are visited in order inside the lane because
 // the orient 2/4 corner rotation of one template leaks into the next.
-// finalise_kernel replaces opencvar.cpp:662-668 and 780-801 (+ cvarSquareToMatrix 524-540) for one frame per
-// workgroup: lane 0 replays the order-dependent elimination, then the survivors' poses are solved one per lane.
+// finalise_kernel replaces opencvar.cpp:662-668 and 780-801 for one frame per workgroup (the order-dependent elimination,
+// replayed 64 comparisons at a time, and the marker records); pose_kernel solves the survivors' poses (cvarSquareToMatrix
+// 524-540), one lane per marker over the whole batch.
 #include "kernels.h"
 
 namespace ocvar {
@@ -107,14 +108,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 
 // (the tail keeps a frame's candidates in LDS: Workspace::maxc of them, 9 bytes each, sized at launch)
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8), amdgpu_num_vgpr(128))) void finalise_kernel(Workspace ws) {
+__global__ __launch_bounds__(64) void finalise_kernel(Workspace ws) {
     extern __shared__ int tail_lds[];
     const int MAXC = ws.maxc;
     int* s_mid = tail_lds;
     int* s_tid = tail_lds + MAXC;
     unsigned char* s_score = reinterpret_cast<unsigned char*>(tail_lds + 2 * MAXC);
     __shared__ int s_src[MAXM];  // >= 0: candidate index, < 0: -(1 + index into prev)
-    __shared__ int s_nout;
+    __shared__ int s_nout, s_job;
     const int f = blockIdx.x;
     const int T = ws.n_templates;
     const int lane = threadIdx.x;   // one wave per frame
@@ -194,26 +195,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
         // `prev` would be cut short and its tracking would diverge from the reference -- fail loudly instead
         if (total > MAXM) atomicOr(ws.counters + CNT_ERR, ERR_MARKER_OVERFLOW);
         ws.n_markers[f] = total;
+        s_job = nout > 0 ? atomicAdd(ws.counters + CNT_POSE_JOBS, nout) : 0;   // one list append per frame
     }
     __syncthreads();
-    const CameraRec cam = *ws.camera;
+    // the surviving markers' records, all but the pose; one pose job per marker for pose_kernel
     for (int k = threadIdx.x; k < s_nout; k += blockDim.x) {
-        MarkerRec m;
+        MarkerRec* m = ws.markers + (size_t)f * MAXM + k;
         const int src = s_src[k];
         if (src < 0) {
-            m = ws.prev[(size_t)f * MAXM + (-src - 1)];  // square already updated by the tracking step
+            *m = ws.prev[(size_t)f * MAXM + (-src - 1)];  // square already updated by the tracking step
         } else {
             const int i = s_mid[src], j = s_tid[src];
             const CandRec* c = ws.cand_recs + ((size_t)f * ws.maxq + i) * MAXT + j;
             const TemplateRec t = ws.templates[j];
-            m.templateId = j;
-            m.markerId = i;
-            m.score = c->orient ? 1.0 : 0.0;
-            for (int q = 0; q < 8; q++) m.square[q] = c->square[q];
-            m.aspectRatio = (double)t.width / t.height;
+            m->templateId = j;
+            m->markerId = i;
+            m->score = c->orient ? 1.0 : 0.0;
+            for (int q = 0; q < 8; q++) m->square[q] = c->square[q];
+            m->aspectRatio = (double)t.width / t.height;
         }
-        square_to_glmatrix(m.square, cam, m.aspectRatio, m.glMatrix);
-        ws.markers[(size_t)f * MAXM + k] = m;
+        ws.pose_jobs[s_job + k] = f * MAXM + k;
+    }
+}
+
+// cvarSquareToMatrix (opencvar.cpp:524-540) for every surviving marker of the batch, one lane each.  Round 2 solved the poses
+// inside the per-frame tail kernel: one 64-lane workgroup per frame with at most 3 lanes in the solver, capped at 128 registers so
+// that it could start between binarise waves -- the solver's arrays lived in scratch memory and the kernel took 1.06 ms per
+// 2048 frames for ~5 k poses.  Here the ~5 k jobs fill ~85 waves, every array of the solver is a register (loops unrolled to
+// constant indices, the seeding homography in closed form: pose_core.h) and the kernel is as long as one solve.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void pose_kernel(Workspace ws) {
+    int n = ws.counters[CNT_POSE_JOBS];
+    const int cap = ws.n_frames * MAXM;
+    if (n > cap) n = cap;
+    const CameraRec cam = *ws.camera;
+    for (int j = blockIdx.x * 64 + threadIdx.x; j < n; j += gridDim.x * 64) {
+        MarkerRec* m = ws.markers + ws.pose_jobs[j];
+        float sq[8];
+        for (int q = 0; q < 8; q++) sq[q] = m->square[q];
+        double gl[16];
+        square_to_glmatrix(sq, cam, m->aspectRatio, gl);
+        for (int q = 0; q < 16; q++) m->glMatrix[q] = gl[q];
     }
 }
 
@@ -222,7 +243,12 @@ void launch_decode(const Workspace& ws, hipStream_t stream) {
         hipLaunchKernelGGL(decode_kernel, dim3(ws.n_frames), dim3(256), (size_t)DECODE_CHUNK * ws.n_templates * 9 * sizeof(double), stream, ws);
 }
 void launch_finalise(const Workspace& ws, hipStream_t stream) {
-    if (ws.n_frames > 0) hipLaunchKernelGGL(finalise_kernel, dim3(ws.n_frames), dim3(64), (size_t)ws.maxc * 9 + 16, stream, ws);
+    if (ws.n_frames <= 0) return;
+    hipLaunchKernelGGL(finalise_kernel, dim3(ws.n_frames), dim3(64), (size_t)ws.maxc * 9 + 16, stream, ws);
+    // a stateless frame keeps at most one marker per template: a grid of one wave per 8 frames takes a batch's poses in one
+    // pass; stateful batches with many tracked markers per frame loop (grid-stride)
+    const int blocks = ws.n_frames / 8 + 1;
+    hipLaunchKernelGGL(pose_kernel, dim3(blocks), dim3(64), 0, stream, ws);
 }
 
 }  // namespace ocvar

@@ -10,9 +10,11 @@
 #include <hip/hip_runtime.h>
 #define OCVAR_HD __host__ __device__ __forceinline__
 #define OCVAR_D __device__ __forceinline__
+#define OCVAR_UNROLL _Pragma("unroll")   // small fixed-size loops over arrays that must become registers (constant indices)
 #else
 #define OCVAR_HD inline
 #define OCVAR_D inline
+#define OCVAR_UNROLL
 #endif
 
 namespace ocvar {

@@ -47,6 +47,7 @@ enum { CNT_FRAME_CANDS = 0, CNT_CROP_ROIS = 1, CNT_CROP_TILES = 2, CNT_CROP_CAND
        CNT_POOL_INTS = 4 /* 64-bit, uses 4..5 */, CNT_CROP_QUADS = 6, CNT_TICKET_F = 7, CNT_TICKET_C = 8, CNT_ERR = 9,
        CNT_CROP_PIXELS = 10 /* 64-bit, uses 10..11 */, CNT_LONG_F = 12, CNT_LONG_C = 13, CNT_TICKET_LF = 14, CNT_TICKET_LC = 15,
        CNT_MID_F = 16, CNT_MID_C = 17, CNT_TICKET_MF = 18, CNT_TICKET_MC = 19, CNT_TICKET_BC = 20, CNT_MID_C_FIRST = 21, CNT_TICKET_MC2 = 22,
+       CNT_POSE_JOBS = 23,
        CNT_PROF = 24 /* 32 64-bit profiling slots, written only by builds with -DOCVAR_PROF (tools/prof_tier2.py) */, CNT_COUNT = 88 };
 
 struct Workspace {
@@ -94,6 +95,7 @@ struct Workspace {
     int* n_prev;            // [B]
     int* reserve;           // [B][MAXM] tracked marker indices
     int* n_reserve;         // [B]
+    int* pose_jobs;         // [B][MAXM] frame * MAXM + slot of every output marker (counter CNT_POSE_JOBS): pose_kernel's work list
     MarkerRec* markers;     // [B][MAXM] output
     int* n_markers;         // [B]
     TemplateRec* templates; // [MAXT]

@@ -26,12 +26,15 @@ struct CameraRec {  // == CvarCamera (include/opencvar/opencvar.h), 248 bytes
     double glProjection[16];
 };
 
-OCVAR_HD void rodrigues(const double* r, double* R, double* J /* 3x9 or null */) {
+template <bool WITH_J>
+OCVAR_HD void rodrigues_t(const double* r, double* R, double* J /* 3x9 when WITH_J */) {
     double rx = r[0], ry = r[1], rz = r[2];
     const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    OCVAR_UNROLL
     for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
     if (theta < DBL_EPSILON) {
-        if (J) {
+        if (WITH_J) {
+            OCVAR_UNROLL
             for (int k = 0; k < 27; k++) J[k] = 0;
             J[5] = J[15] = J[19] = -1;
             J[7] = J[11] = J[21] = 1;
@@ -44,18 +47,26 @@ OCVAR_HD void rodrigues(const double* r, double* R, double* J /* 3x9 or null */)
     rz *= it;
     const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
     const double rx_[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+    OCVAR_UNROLL
     for (int k = 0; k < 9; k++) R[k] = c * R[k] + c1 * rrt[k] + s * rx_[k];
-    if (J) {
+    if (WITH_J) {
         const double drrt[27] = {rx + rx, ry, rz, ry, 0, 0, rz, 0, 0, 0, rx, 0, rx, ry + ry, rz, 0, rz, 0,
                                  0, 0, rx, 0, 0, ry, rx, ry, rz + rz};
         const double drx[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
+        OCVAR_UNROLL
         for (int i = 0; i < 3; i++) {
             const double ri = i == 0 ? rx : (i == 1 ? ry : rz);
             const double a0 = -s * ri, a1 = (s - 2 * c1 * it) * ri, a2 = c1 * it, a3 = (c - s * it) * ri, a4 = s * it;
+            OCVAR_UNROLL
             for (int k = 0; k < 9; k++)
                 J[i * 9 + k] = a0 * ((k % 4 == 0) ? 1.0 : 0.0) + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * rx_[k] + a4 * drx[i * 9 + k];
         }
     }
+}
+
+OCVAR_HD void rodrigues(const double* r, double* R, double* J /* 3x9 or null */) {
+    if (J) rodrigues_t<true>(r, R, J);
+    else rodrigues_t<false>(r, R, nullptr);
 }
 
 // nearest rotation (orthogonal polar factor) by Newton's iteration Q <- (Q + Q^-T)/2
@@ -74,6 +85,7 @@ OCVAR_HD void nearest_rotation(double* Q) {
         const double det = Q[0] * C[0] + Q[1] * C[1] + Q[2] * C[2];
         if (det == 0) return;
         double delta = 0;
+        OCVAR_UNROLL
         for (int k = 0; k < 9; k++) {
             const double n = 0.5 * (Q[k] + C[k] / det);  // cofactor/det = inverse transpose
             delta += (n - Q[k]) * (n - Q[k]);
@@ -85,6 +97,7 @@ OCVAR_HD void nearest_rotation(double* Q) {
 
 OCVAR_HD void rotation_to_rvec(const double* Rin, double* r) {
     double R[9];
+    OCVAR_UNROLL
     for (int k = 0; k < 9; k++) R[k] = Rin[k];
     nearest_rotation(R);
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
@@ -119,48 +132,41 @@ OCVAR_HD void rotation_to_rvec(const double* Rin, double* r) {
     r[2] = rz;
 }
 
-// homography of the marker rectangle (+-ratio, +-1) -> 4 normalised image points, exact 8x8 solve
+// Homography of the marker rectangle (+-ratio, +-1) -> 4 normalised image points.  Four points determine it, so it is written
+// down in closed form (the projective map of the unit square onto a quadrilateral, composed with the rectangle's affine map onto
+// the unit square) instead of eliminating an 8x8 system: no pivot search, no indexed rows -- on the GPU the system's 72 doubles
+// lived in scratch memory and every access was a memory round trip.  Scaled to H[8] = 1 like the solve it replaces; it only
+// seeds the refinement below, which converges to the same minimum (tests/test_device_cores_cpu.py against the oracle's solve).
 OCVAR_HD bool rect_homography(double ratio, const double* m, double* H) {
-    const double MX[4] = {-ratio, ratio, ratio, -ratio}, MY[4] = {-1, -1, 1, 1};
-    double A[8][9];
-    for (int i = 0; i < 4; i++) {
-        const double X = MX[i], Y = MY[i], x = m[2 * i], y = m[2 * i + 1];
-        double* a = A[2 * i];
-        double* b = A[2 * i + 1];
-        a[0] = X; a[1] = Y; a[2] = 1; a[3] = 0; a[4] = 0; a[5] = 0; a[6] = -x * X; a[7] = -x * Y; a[8] = x;
-        b[0] = 0; b[1] = 0; b[2] = 0; b[3] = X; b[4] = Y; b[5] = 1; b[6] = -y * X; b[7] = -y * Y; b[8] = y;
-    }
-    for (int c = 0; c < 8; c++) {
-        int piv = c;
-        for (int r = c + 1; r < 8; r++)
-            if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
-        if (A[piv][c] == 0) return false;
-        for (int k = 0; k < 9; k++) {
-            const double t = A[c][k];
-            A[c][k] = A[piv][k];
-            A[piv][k] = t;
-        }
-        const double inv = 1.0 / A[c][c];
-        for (int k = c; k < 9; k++) A[c][k] *= inv;
-        for (int r = 0; r < 8; r++) {
-            if (r == c) continue;
-            const double f = A[r][c];
-            if (f != 0)
-                for (int k = c; k < 9; k++) A[r][k] -= f * A[c][k];
-        }
-    }
-    for (int i = 0; i < 8; i++) H[i] = A[i][8];
-    H[8] = 1;
+    const double x0 = m[0], y0 = m[1], x1 = m[2], y1 = m[3], x2 = m[4], y2 = m[5], x3 = m[6], y3 = m[7];
+    // unit square (0,0) (1,0) (1,1) (0,1) -> p0 p1 p2 p3
+    const double dx1 = x1 - x2, dy1 = y1 - y2, dx2 = x3 - x2, dy2 = y3 - y2, sx = x0 - x1 + x2 - x3, sy = y0 - y1 + y2 - y3;
+    const double den = dx1 * dy2 - dx2 * dy1;
+    if (den == 0) return false;
+    const double g = (sx * dy2 - dx2 * sy) / den, h = (dx1 * sy - sx * dy1) / den;
+    const double a = x1 - x0 + g * x1, b = x3 - x0 + h * x3, c = x0;
+    const double d = y1 - y0 + g * y1, e = y3 - y0 + h * y3, f = y0;
+    // rectangle -> unit square: u = (X + ratio) / (2 ratio), v = (Y + 1) / 2
+    const double iu = 0.5 / ratio, iv = 0.5;
+    const double h0 = a * iu, h1 = b * iv, h2 = a * 0.5 + b * 0.5 + c;
+    const double h3 = d * iu, h4 = e * iv, h5 = d * 0.5 + e * 0.5 + f;
+    const double h6 = g * iu, h7 = h * iv, h8 = g * 0.5 + h * 0.5 + 1.0;
+    if (h8 == 0) return false;
+    const double s = 1.0 / h8;
+    H[0] = h0 * s; H[1] = h1 * s; H[2] = h2 * s;
+    H[3] = h3 * s; H[4] = h4 * s; H[5] = h5 * s;
+    H[6] = h6 * s; H[7] = h7 * s; H[8] = 1;
     return true;
 }
 
 // reprojection of the 4 rectangle corners, residual e = proj - img, optional 8x6 Jacobian.  dist: k1 k2 p1 p2 k3 or null
 // (pinhole).
-OCVAR_HD void reproject(double ratio, const double* p, const double* K, const double* dist, const double* img, double* e, double* J) {
+template <bool WITH_J, bool DIST>
+OCVAR_HD void reproject_t(double ratio, const double* p, double fx, double fy, double cx, double cy, const double* dist, const double* img, double* e, double* J) {
     double R[9], dR[27];
-    rodrigues(p, R, J ? dR : nullptr);
-    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    rodrigues_t<WITH_J>(p, R, dR);
     const double MX[4] = {-ratio, ratio, ratio, -ratio}, MY[4] = {-1, -1, 1, 1};
+    OCVAR_UNROLL
     for (int i = 0; i < 4; i++) {
         const double X = MX[i], Y = MY[i];
         double x = R[0] * X + R[1] * Y + p[3];
@@ -169,12 +175,13 @@ OCVAR_HD void reproject(double ratio, const double* p, const double* K, const do
         z = z ? 1. / z : 1;
         x *= z;
         y *= z;
-        if (!dist) {
+        if (!DIST) {
             e[2 * i] = x * fx + cx - img[2 * i];
             e[2 * i + 1] = y * fy + cy - img[2 * i + 1];
-            if (J) {
+            if (WITH_J) {
                 double* jx = J + 12 * i;
                 double* jy = jx + 6;
+                OCVAR_UNROLL
                 for (int j = 0; j < 3; j++) {
                     const double* d = dR + 9 * j;
                     const double dx0 = X * d[0] + Y * d[1], dy0 = X * d[3] + Y * d[4], dz0 = X * d[6] + Y * d[7];
@@ -194,13 +201,14 @@ OCVAR_HD void reproject(double ratio, const double* p, const double* K, const do
         const double yd = y * cd + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
         e[2 * i] = xd * fx + cx - img[2 * i];
         e[2 * i + 1] = yd * fy + cy - img[2 * i + 1];
-        if (J) {
+        if (WITH_J) {
             double* jx = J + 12 * i;
             double* jy = jx + 6;
             // partial derivatives of the distorted point with respect to the undistorted one
             const double dcd = 2 * (k1 + (2 * k2 + 3 * k3 * r2) * r2);   // d(cd)/d(r2) * 2: d(cd) = dcd * (x dx + y dy)
             const double xdx = cd + x * x * dcd + 2 * p1 * y + 6 * p2 * x, xdy = x * y * dcd + 2 * p1 * x + 2 * p2 * y;
             const double ydx = x * y * dcd + 2 * p1 * x + 2 * p2 * y, ydy = cd + y * y * dcd + 6 * p1 * y + 2 * p2 * x;
+            OCVAR_UNROLL
             for (int j = 0; j < 6; j++) {
                 double dx, dy;
                 if (j < 3) {
@@ -219,12 +227,25 @@ OCVAR_HD void reproject(double ratio, const double* p, const double* K, const do
     }
 }
 
+OCVAR_HD void reproject(double ratio, const double* p, const double* K, const double* dist, const double* img, double* e, double* J) {
+    if (dist) {
+        if (J) reproject_t<true, true>(ratio, p, K[0], K[4], K[2], K[5], dist, img, e, J);
+        else reproject_t<false, true>(ratio, p, K[0], K[4], K[2], K[5], dist, img, e, nullptr);
+    } else {
+        if (J) reproject_t<true, false>(ratio, p, K[0], K[4], K[2], K[5], nullptr, img, e, J);
+        else reproject_t<false, false>(ratio, p, K[0], K[4], K[2], K[5], nullptr, img, e, nullptr);
+    }
+}
+
 // solves A x = b for symmetric positive definite 6x6 A (Cholesky); false if not positive definite
 OCVAR_HD bool chol6(const double* A, const double* b, double* x) {
     double L[36];
+    OCVAR_UNROLL
     for (int i = 0; i < 6; i++)
+        OCVAR_UNROLL
         for (int j = 0; j <= i; j++) {
             double s = A[i * 6 + j];
+            OCVAR_UNROLL
             for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
             if (i == j) {
                 if (!(s > 0)) return false;
@@ -234,13 +255,17 @@ OCVAR_HD bool chol6(const double* A, const double* b, double* x) {
             }
         }
     double y[6];
+    OCVAR_UNROLL
     for (int i = 0; i < 6; i++) {
         double s = b[i];
+        OCVAR_UNROLL
         for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k];
         y[i] = s / L[i * 6 + i];
     }
+    OCVAR_UNROLL
     for (int i = 5; i >= 0; i--) {
         double s = y[i];
+        OCVAR_UNROLL
         for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k];
         x[i] = s / L[i * 6 + i];
     }
@@ -249,14 +274,18 @@ OCVAR_HD bool chol6(const double* A, const double* b, double* x) {
 
 OCVAR_HD double norm_n(const double* v, int n) {
     double s = 0;
+    OCVAR_UNROLL
     for (int i = 0; i < n; i++) s += v[i] * v[i];
     return sqrt(s);
 }
 
 OCVAR_HD void gl_from_pose(const double* R, const double* t, double* m) {
     // cvarGlMatrix: m = R^T laid out in 4x4, through a quaternion with x,y negated, then translation.
+    OCVAR_UNROLL
     for (int k = 0; k < 16; k++) m[k] = 0;
+    OCVAR_UNROLL
     for (int j = 0; j < 3; j++)
+        OCVAR_UNROLL
         for (int i = 0; i < 3; i++) m[i * 4 + j] = R[j * 3 + i];
     double x, y, z, w, s;
     const double tr = 1 + m[0] + m[5] + m[10];
@@ -303,16 +332,17 @@ OCVAR_HD void gl_from_pose(const double* R, const double* t, double* m) {
     m[15] = 1;
 }
 
-OCVAR_HD void square_to_glmatrix(const float* sq, const CameraRec& cam, double ratio, double* gl) {
-    const double* K = cam.cameraMatrix;
-    const double* kd = cam.distCoeffs;
-    const double* dist = (kd[0] != 0 || kd[1] != 0 || kd[2] != 0 || kd[3] != 0 || kd[4] != 0) ? kd : nullptr;
+// fx, fy, cx, cy: the intrinsics; dist: k1 k2 p1 p2 k3 (read only when DIST)
+template <bool DIST>
+OCVAR_HD void square_to_glmatrix_t(const float* sq, double fx, double fy, double cx, double cy, const double* dist, double ratio, double* gl) {
+    const double K[6] = {fx, 0, cx, 0, fy, cy};
     double img[8], mn[8];
+    OCVAR_UNROLL
     for (int i = 0; i < 4; i++) {
         img[2 * i] = sq[2 * i];
         img[2 * i + 1] = sq[2 * i + 1];
         double x = (img[2 * i] - K[2]) * (1. / K[0]), y = (img[2 * i + 1] - K[5]) * (1. / K[4]);
-        if (dist) {   // cvUndistortPoints: 5 fixed-point iterations of the inverse distortion
+        if (DIST) {   // cvUndistortPoints: 5 fixed-point iterations of the inverse distortion
             const double x0 = x, y0 = y;
             for (int it = 0; it < 5; it++) {
                 const double r2 = x * x + y * y;
@@ -336,7 +366,7 @@ OCVAR_HD void square_to_glmatrix(const float* sq, const CameraRec& cam, double r
         // Rodrigues round trip (orthonormalise), then matrix -> vector once more as OpenCV does
         double rv[3];
         rotation_to_rvec(Rm, rv);
-        rodrigues(rv, Rm, nullptr);
+        rodrigues_t<false>(rv, Rm, nullptr);
         rotation_to_rvec(Rm, p);
         p[3] = h[2] * s3;
         p[4] = h[5] * s3;
@@ -347,42 +377,59 @@ OCVAR_HD void square_to_glmatrix(const float* sq, const CameraRec& cam, double r
     int lambdaLg10 = -3;
     double prevErr = DBL_MAX;
     for (int iters = 0;;) {
-        reproject(ratio, p, K, dist, img, e, J);
+        reproject_t<true, DIST>(ratio, p, fx, fy, cx, cy, dist, img, e, J);
+        OCVAR_UNROLL
         for (int i = 0; i < 6; i++) {
+            OCVAR_UNROLL
             for (int j = 0; j < 6; j++) {
                 double s = 0;
+                OCVAR_UNROLL
                 for (int k = 0; k < 8; k++) s += J[k * 6 + i] * J[k * 6 + j];
                 JtJ[i * 6 + j] = s;
             }
             double s = 0;
+            OCVAR_UNROLL
             for (int k = 0; k < 8; k++) s += J[k * 6 + i] * e[k];
             Jte[i] = s;
         }
+        OCVAR_UNROLL
         for (int i = 0; i < 6; i++) prev[i] = p[i];
         if (iters == 0) prevErr = norm_n(e, 8);
         double errNorm;
         for (bool first = true;; first = false) {
             if (!first) {
-                reproject(ratio, p, K, dist, img, e, nullptr);
+                reproject_t<false, DIST>(ratio, p, fx, fy, cx, cy, dist, img, e, nullptr);
                 errNorm = norm_n(e, 8);
                 if (!(errNorm > prevErr && ++lambdaLg10 <= 16)) break;
             }
             const double lambda = exp(lambdaLg10 * 2.302585092994046);
+            OCVAR_UNROLL
             for (int k = 0; k < 36; k++) N[k] = JtJ[k];
+            OCVAR_UNROLL
             for (int i = 0; i < 6; i++) N[i * 7] *= 1. + lambda;
             if (!chol6(N, Jte, dx))
+                OCVAR_UNROLL
                 for (int i = 0; i < 6; i++) dx[i] = 0;
+            OCVAR_UNROLL
             for (int i = 0; i < 6; i++) p[i] = prev[i] - dx[i];
         }
         lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
         double d[6];
+        OCVAR_UNROLL
         for (int i = 0; i < 6; i++) d[i] = p[i] - prev[i];
         if (++iters >= 20 || norm_n(d, 6) / norm_n(prev, 6) < FLT_EPSILON) break;
         prevErr = errNorm;
     }
     double R[9];
-    rodrigues(p, R, nullptr);
+    rodrigues_t<false>(p, R, nullptr);
     gl_from_pose(R, p + 3, gl);
+}
+
+OCVAR_HD void square_to_glmatrix(const float* sq, const CameraRec& cam, double ratio, double* gl) {
+    const double fx = cam.cameraMatrix[0], fy = cam.cameraMatrix[4], cx = cam.cameraMatrix[2], cy = cam.cameraMatrix[5];
+    const double kd[5] = {cam.distCoeffs[0], cam.distCoeffs[1], cam.distCoeffs[2], cam.distCoeffs[3], cam.distCoeffs[4]};
+    if (kd[0] != 0 || kd[1] != 0 || kd[2] != 0 || kd[3] != 0 || kd[4] != 0) square_to_glmatrix_t<true>(sq, fx, fy, cx, cy, kd, ratio, gl);
+    else square_to_glmatrix_t<false>(sq, fx, fy, cx, cy, kd, ratio, gl);
 }
 
 }  // namespace ocvar
