@@ -12,37 +12,38 @@
 
 namespace ocvar {
 
-// Two phases per chunk of 32 frame-pass quads, one workgroup per frame.  Phase 1, one lane per (quad, template): the
-// inverse homography (8x8 solve in double; the destination quad is (tw+2) x (th+2), so it depends on the template) into
-// LDS.  Phase 2, one wave per quad and one lane per code cell: lane L samples the cell whose bit is bit L of the code --
-// acArray2DToBit packs row-major, columns right to left, first cell in the most significant bit (acmath.cpp:546-554) --
-// so the code is the ballot of the thresholded samples.  (One lane per quad walked ~77 dependent samples per quad;
-// one wave per quad for everything repeats the solve 64 times over.)
-constexpr int DECODE_CHUNK = 32;
+// One wave per (frame, quarter of the frame's quads): workgroups of 64 threads, because with several contexts in flight a
+// workgroup has to fit into the gap one retiring binarise wave leaves (round 2's 256-thread workgroups at 128 registers took 5 ms
+// in-region for 0.3 ms of work).  Two phases per chunk of 8 quads.  Phase 1, one lane per (quad, template): the inverse
+// homography (closed form in double, rounded to float32 and inverted; the destination quad is (tw+2) x (th+2), so it depends on
+// the template) into LDS.  Phase 2, quad by quad, one lane per code cell: lane L samples the cell whose bit is bit L of the
+// code -- acArray2DToBit packs row-major, columns right to left, first cell in the most significant bit (acmath.cpp:546-554)
+// -- so the code is the ballot of the thresholded samples.
+constexpr int DECODE_SLICES = 4;   // waves per frame: quad i belongs to slice i % 4
+constexpr int DECODE_CHUNK = 8;    // quads of a slice per phase-1 round (x templates <= 64 lanes for up to 8 templates; more: lanes loop)
 
-// (register budget of 4 waves per SIMD = 128 VGPRs and LDS sized by the actual template count: with several contexts in
-// flight the binarise kernels fill the SIMDs, and a workgroup that needs more waits until most of them have drained)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void decode_kernel(Workspace ws) {
+__global__ __launch_bounds__(64) void decode_kernel(Workspace ws) {
     extern __shared__ double sM_dyn[];   // [DECODE_CHUNK][n_templates][9]
     __shared__ int s_roi[DECODE_CHUNK];        // crop ROI of the chunk's quad, -1: no quad in its crop
     __shared__ unsigned s_slot[DECODE_CHUNK];  // quads_crop slot of the crop's quad
-    const int f = blockIdx.x;
-    const int tid = threadIdx.x, lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int f = blockIdx.x / DECODE_SLICES, slice = blockIdx.x % DECODE_SLICES;
+    const int lane = threadIdx.x;
     const int T = ws.n_templates;
     int nsq = ws.n_squares[f];
     nsq = nsq < ws.maxq ? nsq : ws.maxq;
-    for (int base = 0; base < nsq; base += DECODE_CHUNK) {
-        const int cnt = nsq - base < DECODE_CHUNK ? nsq - base : DECODE_CHUNK;
-        if (tid < cnt) {
-            const int r = ws.crop_of[(size_t)f * ws.maxq + base + tid];
+    const int mine = (nsq - slice + DECODE_SLICES - 1) / DECODE_SLICES;   // quads slice, slice + 4, ... < nsq
+    for (int base = 0; base < mine; base += DECODE_CHUNK) {
+        const int cnt = mine - base < DECODE_CHUNK ? mine - base : DECODE_CHUNK;
+        if (lane < cnt) {
+            const int i = slice + DECODE_SLICES * (base + lane);
+            const int r = ws.crop_of[(size_t)f * ws.maxq + i];
             unsigned long long best = ~0ull;
             if (r >= 0) best = ws.best_crop[r];
-            s_roi[tid] = best == ~0ull ? -1 : r;
-            s_slot[tid] = (unsigned)(best & 0xffffffffu);
+            s_roi[lane] = best == ~0ull ? -1 : r;
+            s_slot[lane] = (unsigned)(best & 0xffffffffu);
         }
         __syncthreads();
-        for (int pair = tid; pair < cnt * T; pair += blockDim.x) {
+        for (int pair = lane; pair < cnt * T; pair += 64) {
             const int qi = pair / T, j = pair - qi * T;
             if (s_roi[qi] < 0) continue;
             const QuadRec q = ws.quads_crop[s_slot[qi]];
@@ -56,8 +57,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             for (int k = 0; k < 9; k++) sM_dyn[(qi * T + j) * 9 + k] = M[k];
         }
         __syncthreads();
-        for (int qi = wave; qi < cnt; qi += 4) {
-            const int i = base + qi;
+        for (int qi = 0; qi < cnt; qi++) {
+            const int i = slice + DECODE_SLICES * (base + qi);
             CandRec* out = ws.cand_recs + ((size_t)f * ws.maxq + i) * MAXT;
             const int r = s_roi[qi];
             if (r < 0) {  // no quad in the crop: no candidate for this square (opencvar.cpp:704)
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 void launch_decode(const Workspace& ws, hipStream_t stream) {
     if (ws.n_frames > 0)
-        hipLaunchKernelGGL(decode_kernel, dim3(ws.n_frames), dim3(256), (size_t)DECODE_CHUNK * ws.n_templates * 9 * sizeof(double), stream, ws);
+        hipLaunchKernelGGL(decode_kernel, dim3(ws.n_frames * DECODE_SLICES), dim3(64), (size_t)DECODE_CHUNK * ws.n_templates * 9 * sizeof(double), stream, ws);
 }
 void launch_finalise(const Workspace& ws, hipStream_t stream) {
     if (ws.n_frames <= 0) return;

@@ -20,45 +20,33 @@ struct TemplateRec {  // == CvarTemplate (include/opencvar/opencvar.h), 48 bytes
     long long code[4];
 };
 
-// 8x8 DLT system, Gaussian elimination with partial pivoting, double; result rounded to float32.
+// cvGetPerspectiveTransform(src quad -> (0,0) (W-1,0) (W-1,H-1) (0,H-1)), in double, rounded to float32.  Four point pairs
+// determine the map, so it is written down in closed form instead of eliminating the 8x8 system: the projective map of the
+// unit square onto the source quad (Heckbert), scaled to the destination rectangle, inverted by its adjugate and normalised to
+// m[8] = 1.  No pivot search and no indexed rows: on the GPU the system's 72 doubles lived in scratch memory.  (OpenCV 2.4
+// solves by SVD, the oracle by Jacobi SVD, round 2's device code by Gaussian elimination: three roundings of the same
+// rational function, equal after the cast to float32 up to rare last-bit ties -- tools/fuzz_parity.py compares every decoded
+// code, orientation and corner with the oracle.)
 OCVAR_HD bool perspective_from_quad(const float* src, int W, int H, float* m) {
-    const float dst[8] = {0.f, 0.f, (float)(W - 1), 0.f, (float)(W - 1), (float)(H - 1), 0.f, (float)(H - 1)};
-    double A[8][9];
-    for (int i = 0; i < 4; i++) {
-        const double sx = src[2 * i], sy = src[2 * i + 1], dx = dst[2 * i], dy = dst[2 * i + 1];
-        A[i][0] = sx; A[i][1] = sy; A[i][2] = 1; A[i][3] = 0; A[i][4] = 0; A[i][5] = 0;
-        A[i][6] = -sx * dx; A[i][7] = -sy * dx; A[i][8] = dx;
-        A[i + 4][0] = 0; A[i + 4][1] = 0; A[i + 4][2] = 0; A[i + 4][3] = sx; A[i + 4][4] = sy; A[i + 4][5] = 1;
-        A[i + 4][6] = -sx * dy; A[i + 4][7] = -sy * dy; A[i + 4][8] = dy;
-    }
-    for (int c = 0; c < 8; c++) {
-        int piv = c;
-        double best = fabs(A[c][c]);
-        for (int r = c + 1; r < 8; r++) {
-            const double v = fabs(A[r][c]);
-            if (v > best) {
-                best = v;
-                piv = r;
-            }
-        }
-        if (best == 0.0) return false;
-        if (piv != c)
-            for (int k = 0; k < 9; k++) {
-                const double t = A[c][k];
-                A[c][k] = A[piv][k];
-                A[piv][k] = t;
-            }
-        for (int r = c + 1; r < 8; r++) {
-            const double f = A[r][c] / A[c][c];
-            for (int k = c; k < 9; k++) A[r][k] = A[r][k] - f * A[c][k];
-        }
-    }
-    for (int c = 7; c >= 0; c--) {
-        double s = A[c][8];
-        for (int k = c + 1; k < 8; k++) s = s - A[c][k] * A[k][8];
-        A[c][8] = s / A[c][c];
-    }
-    for (int i = 0; i < 8; i++) m[i] = (float)A[i][8];
+    const double x0 = src[0], y0 = src[1], x1 = src[2], y1 = src[3], x2 = src[4], y2 = src[5], x3 = src[6], y3 = src[7];
+    const double dx1 = x1 - x2, dy1 = y1 - y2, dx2 = x3 - x2, dy2 = y3 - y2, sx = x0 - x1 + x2 - x3, sy = y0 - y1 + y2 - y3;
+    const double den = dx1 * dy2 - dx2 * dy1;
+    if (den == 0.0 || W < 2 || H < 2) return false;
+    const double g = (sx * dy2 - dx2 * sy) / den, h = (dx1 * sy - sx * dy1) / den;
+    // unit square -> quad, with the rectangle's scale folded in: (X, Y) = ((W-1) u, (H-1) v)
+    const double iu = 1.0 / (double)(W - 1), iv = 1.0 / (double)(H - 1);
+    const double a = (x1 - x0 + g * x1) * iu, b = (x3 - x0 + h * x3) * iv, c = x0;
+    const double d = (y1 - y0 + g * y1) * iu, e = (y3 - y0 + h * y3) * iv, f = y0;
+    const double gg = g * iu, hh = h * iv;
+    // inverse of [a b c; d e f; gg hh 1] up to scale: the adjugate
+    const double A0 = e - f * hh, A1 = c * hh - b, A2 = b * f - c * e;
+    const double A3 = f * gg - d, A4 = a - c * gg, A5 = c * d - a * f;
+    const double A6 = d * hh - e * gg, A7 = b * gg - a * hh, A8 = a * e - b * d;
+    if (A8 == 0.0) return false;
+    const double s = 1.0 / A8;
+    m[0] = (float)(A0 * s); m[1] = (float)(A1 * s); m[2] = (float)(A2 * s);
+    m[3] = (float)(A3 * s); m[4] = (float)(A4 * s); m[5] = (float)(A5 * s);
+    m[6] = (float)(A6 * s); m[7] = (float)(A7 * s);
     m[8] = 1.0f;
     return true;
 }

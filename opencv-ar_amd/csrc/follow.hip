@@ -51,6 +51,13 @@ __device__ __forceinline__ double uni(double v) { return __longlong_as_double((l
 #define PROF_FLUSH(base) do { } while (0)
 #endif
 
+// Waves per workgroup of the follower kernels.  Their waves are independent (no barrier after the table set-up), so a workgroup
+// is ONE wave: with several contexts in flight the GPU is full of another context's binarise workgroups, whose retiring waves
+// free 80 registers on one SIMD at a time -- a 4-wave workgroup must find room on all four SIMDs of a CU at once (and four times
+// the LDS) and waits for it (round 2: tier 3 took 4 ms in-region for 0.3 ms of work), a 1-wave workgroup takes the first gap.
+constexpr int FW = 1;
+constexpr int FOLLOW_THREADS = 64 * FW;
+
 // geometry of the ROI a start belongs to
 struct PlaneRef {
     const uint8_t* nbr;
@@ -523,7 +530,7 @@ constexpr int T1_TICKET = 512;
 constexpr int T1_OUT = 128;
 
 template <bool CROP>
-__global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
+__global__ __launch_bounds__(FOLLOW_THREADS) void follow_kernel(Workspace ws) {
     const StartCand* cands = CROP ? ws.cands_crop : ws.cands_frame;
     int n = ws.counters[CROP ? CNT_CROP_CANDS : CNT_FRAME_CANDS];
     const int cap = CROP ? ws.cap_crop_cands : ws.cap_frame_cands;
@@ -537,8 +544,8 @@ __global__ __launch_bounds__(256) void follow_kernel(Workspace ws) {
     // would spend the full budget with almost all lanes idle.  So fresh starts first get the run test and PRE_STEPS steps
     // each, the survivors are queued per wave in LDS, and the full-budget follow only ever runs on (nearly) full waves of
     // survivors.
-    __shared__ StartCand wqueue[4][128];
-    __shared__ StartCand obuf[4][3][T1_OUT];   // routed starts waiting for their append: to tier 2, to tier 3, to tier 2's "first" list
+    __shared__ StartCand wqueue[FW][128];
+    __shared__ StartCand obuf[FW][3][T1_OUT];   // routed starts waiting for their append: to tier 2, to tier 3, to tier 2's "first" list
     int o_n0 = 0, o_n1 = 0, o_n2 = 0;          // wave-uniform fill levels
     auto append = [&](int t, int& o_n) {       // one atomic for everything collected for target t
         if (o_n == 0) return;
@@ -738,9 +745,9 @@ static_assert(FLUSH_W >= MID_BLOCK && 64 % FLUSH_W == 0, "a group of lanes cover
 // what is left and skips every start behind its crop's best quad -- the outline's other side, the code cells, and the
 // staircase starts inside them: about half of a crop's steps.  Frames keep all their quads: one launch, phase 0.
 template <bool CROP>
-__global__ __launch_bounds__(256) void follow_mid_kernel(Workspace ws, int phase) {
-    __shared__ WaveScratch scratch[4];
-    __shared__ unsigned parked[4][64 * POINT_ROW];
+__global__ __launch_bounds__(FOLLOW_THREADS) void follow_mid_kernel(Workspace ws, int phase) {
+    __shared__ WaveScratch scratch[FW];
+    __shared__ unsigned parked[FW][64 * POINT_ROW];
     __shared__ unsigned step_tab[64];
     if (threadIdx.x < 64u) step_tab[threadIdx.x] = lean_table_entry(threadIdx.x);
     __syncthreads();
@@ -1104,10 +1111,10 @@ __device__ LeanTrace trace_lean_tiled(TileCache& t, int cpos, int is_hole, int* 
 }
 
 template <bool CROP>
-__global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
-    __shared__ __attribute__((aligned(16))) uint8_t tiles[4][TILE * TILE];
-    __shared__ WaveScratch scratch[4];
-    __shared__ unsigned staged[4][LDS_PTS];
+__global__ __launch_bounds__(FOLLOW_THREADS) void follow_long_kernel(Workspace ws) {
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[FW][TILE * TILE];
+    __shared__ WaveScratch scratch[FW];
+    __shared__ unsigned staged[FW][LDS_PTS];
     const StartCand* longs = CROP ? ws.long_crop : ws.long_frame;
     int n = ws.counters[CROP ? CNT_LONG_C : CNT_LONG_F];
     if (n > ws.cap_long) n = ws.cap_long;
@@ -1115,7 +1122,7 @@ __global__ __launch_bounds__(256) void follow_long_kernel(Workspace ws) {
     const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6));
     // this wave's point space in global memory
-    int* slab = ws.slab3 + ((size_t)blockIdx.x * 4 + wave) * SLAB3_STRIDE;
+    int* slab = ws.slab3 + ((size_t)blockIdx.x * FW + wave) * SLAB3_STRIDE;
     // a ticket is issued at most n + (waves of the grid) times: more iterations than that means the loop's control flow is
     // broken (see ticket_lane()); report instead of spinning
     for (int guard = n + 2;; guard--) {
@@ -1254,27 +1261,27 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
 }
 
 void launch_follow_frames(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(follow_kernel<false>, dim3(ws.short_blocks), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL(follow_kernel<false>, dim3(ws.short_blocks * (4 / FW)), dim3(FOLLOW_THREADS), 0, stream, ws);
 }
 void launch_follow_crops(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(follow_kernel<true>, dim3(ws.short_blocks), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL(follow_kernel<true>, dim3(ws.short_blocks * (4 / FW)), dim3(FOLLOW_THREADS), 0, stream, ws);
 }
 void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(follow_mid_kernel<false>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 0);
+    hipLaunchKernelGGL(follow_mid_kernel<false>, dim3(ws.mid_blocks * (4 / FW)), dim3(FOLLOW_THREADS), 0, stream, ws, 0);
 }
 void launch_follow_mid_crops(const Workspace& ws, hipStream_t stream) {
     if (ws.crop_phases == 1) {
-        hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 0);
+        hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks * (4 / FW)), dim3(FOLLOW_THREADS), 0, stream, ws, 0);
         return;
     }
-    hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 1);
-    hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks), dim3(256), 0, stream, ws, 2);
+    hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks * (4 / FW)), dim3(FOLLOW_THREADS), 0, stream, ws, 1);
+    hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks * (4 / FW)), dim3(FOLLOW_THREADS), 0, stream, ws, 2);
 }
 void launch_follow_long_frames(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(follow_long_kernel<false>, dim3(ws.long_blocks), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL(follow_long_kernel<false>, dim3(ws.long_blocks * (4 / FW)), dim3(FOLLOW_THREADS), 0, stream, ws);
 }
 void launch_follow_long_crops(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(follow_long_kernel<true>, dim3(ws.long_blocks), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL(follow_long_kernel<true>, dim3(ws.long_blocks * (4 / FW)), dim3(FOLLOW_THREADS), 0, stream, ws);
 }
 void launch_order_and_crops(const Workspace& ws, hipStream_t stream) {
     if (ws.n_frames > 0) hipLaunchKernelGGL(order_and_crops_kernel, dim3(ws.n_frames), dim3(256), (size_t)ws.maxq * 9 * sizeof(int), stream, ws);
