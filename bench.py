@@ -301,10 +301,10 @@ def main():
         dom = max(kernels, key=lambda k: k[2])
         ach = dom[2] / (stage_ms[dom[1]] * 1e-3) / 1e9
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if os.path.exists(tf):   # HBM bytes per frame from rocprofv3 PMC passes (tools/collect_traffic.py), scaled to a launch
+        tf = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if os.path.exists(tf):   # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this launch size (tools/collect_traffic.py)
             t = json.load(open(tf)).get(dom[0].split("<")[0] if dom[0].startswith("binarise") else dom[0])
-            if t and t.get("width") == W and t.get("height") == Hh:
+            if t and t.get("width") == W and t.get("height") == Hh and t.get("frames_per_launch") == int(Bs):
                 traffic = round(t["hbm_bytes_per_frame"] * Bs)
         out = {
             "metric": "frames/sec at 1920x1080, 16 markers/frame; 1/2/4/8 MI355X", "value": round(fps, 2), "unit": "frames/s",

@@ -363,7 +363,11 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
         // and three 360-row chunks per 1080p frame were 20 % slower than eight 136-row ones at 256 frames.)
         int chunks = (w.sh + 64) / 128;
         if (chunks < 1) chunks = 1;
-        const long long min_units = tuned(c, OCVAR_TUNE_MIN_UNITS, "OCVAR_MIN_UNITS", 65536);
+        // (a context that shares the GPU -- it has a gate -- takes the tallest chunks that still give 16 K units: at 2048 frames one
+        // 1080-row chunk per strip.  Alone that launch is 8 % slower than four 272-row chunks, 5.9 against 5.4 ms -- fewer, longer
+        // waves hide less --, with four contexts in flight it is the faster one: 192 against 185 k frames/s, fewer halo rows and
+        // fewer workgroup turnovers for the other contexts' kernels to queue behind)
+        const long long min_units = tuned(c, OCVAR_TUNE_MIN_UNITS, "OCVAR_MIN_UNITS", c->gate ? 16384 : 65536);
         while (chunks > 1 && (long long)w.frame_strips * (chunks / 2) * n_frames >= min_units) chunks /= 2;
         int rows = (w.sh + chunks - 1) / chunks;
         rows = (rows + 7) & ~7;   // whole mask tiles (8 rows) per work unit: binarise.hip writes the mask plane tile by tile

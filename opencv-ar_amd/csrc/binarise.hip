@@ -65,8 +65,7 @@ constexpr unsigned K2(unsigned lo, unsigned hi) { return lo | (hi << 16); }
 __device__ __forceinline__ unsigned alignb(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 __device__ __forceinline__ unsigned byte_of(unsigned v, int j) { return (v >> (8 * j)) & 255u; }
 
-// BGR2GRAY with 8-bit coefficient halves: 1868 = 7*256+76, 9617 = 37*256+145, 4899 = 19*256+35
-__device__ __forceinline__ unsigned grey_px(unsigned w, unsigned khi, unsigned klo) { return (dot4(w, khi, 0) * 256u + dot4(w, klo, 8192u)) >> 14; }
+
 
 // ---- neighbour masks and border starts by table ---------------------------------------------------------------------
 // A lane's 4 threshold bits of one row plus the bits next to them form a 7-bit window: bit 0 = column c0-1 (the left
@@ -251,12 +250,18 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     };
     auto to_grey = [&](const Raw& r) -> unsigned {
         if (!BGR) return r.d0;
-        const unsigned KH = 7u | (37u << 8) | (19u << 16), KL = 76u | (145u << 8) | (35u << 16);
-        const unsigned g0 = grey_px(r.d0, KH, KL);                       // bytes b0 g0 r0 (x)
-        const unsigned g1 = grey_px(alignb(r.d1, r.d0, 3), KH, KL);      // b1 g1 r1 (x)
-        const unsigned g2 = grey_px(alignb(r.d2, r.d1, 2), KH, KL);      // b2 g2 r2 (x)
-        const unsigned g3 = grey_px(r.d2, KH << 8, KL << 8);             // (x) b3 g3 r3
-        return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+        // (1868 B + 9617 G + 4899 R + 8192) >> 14 with everything times four: (7472 B + 38468 G + 19596 R + 32768) >> 16 -- the
+        // grey value is then BYTE 2 of the sum (< 2^24), which a byte permute picks: no shift per pixel.  Coefficient halves for
+        // v_dot4_u32_u8: 7472 = 29*256+48, 38468 = 150*256+68, 19596 = 76*256+140.
+        const unsigned KH = 29u | (150u << 8) | (76u << 16), KL = 48u | (68u << 8) | (140u << 16);
+        const unsigned s0 = (dot4(r.d0, KH, 0u) << 8) + dot4(r.d0, KL, 32768u);                          // bytes b0 g0 r0 (x)
+        const unsigned w1 = alignb(r.d1, r.d0, 3), w2 = alignb(r.d2, r.d1, 2);
+        const unsigned s1 = (dot4(w1, KH, 0u) << 8) + dot4(w1, KL, 32768u);                              // b1 g1 r1 (x)
+        const unsigned s2 = (dot4(w2, KH, 0u) << 8) + dot4(w2, KL, 32768u);                              // b2 g2 r2 (x)
+        const unsigned s3 = (dot4(r.d2, KH << 8, 0u) << 8) + dot4(r.d2, KL << 8, 32768u);                // (x) b3 g3 r3
+        const unsigned g01 = __builtin_amdgcn_perm(s1, s0, 0x0c0c0602u);   // byte 2 of s0, byte 2 of s1, 0, 0
+        const unsigned g23 = __builtin_amdgcn_perm(s3, s2, 0x0c0c0602u);
+        return g01 | (g23 << 16);
     };
 
     const int qa = Y0 / 2 - 3, qb = (Y1 + 3) / 2 + 1;
@@ -448,8 +453,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     __shared__ uint4 tab[128];
     if (threadIdx.x < 128) tab[threadIdx.x] = mask_table_entry(threadIdx.x);
     __syncthreads();
-    const int unit = blockIdx.x * 4 + wave_uniform((int)(threadIdx.x >> 6));
     const int per_frame = ws.frame_strips * ws.frame_chunks;
+    // XCD-aware order.  Consecutive workgroups go round the 8 XCDs, each with its own L2; in launch order the workgroups of one
+    // frame -- neighbouring strips and chunks, which share halo columns and rows -- would land on 8 different L2s and every halo
+    // would be fetched from the fabric twice.  Workgroup b therefore works on frame-group (b / 8) / G, frame b % 8 of that group,
+    // workgroup (b / 8) % G of that frame (G workgroups per frame): a frame's workgroups run on one XCD, next to each other in
+    // time.  (Only when a frame is a whole number of workgroups; the frames beyond the last group of 8 keep launch order.)
+    int wg = (int)blockIdx.x;
+    if ((per_frame & 3) == 0) {
+        const int G = per_frame >> 2, grouped = (ws.n_frames & ~7) * G;
+        if (wg < grouped) {
+            const int k = wg >> 3;
+            wg = ((k / G) * 8 + (wg & 7)) * G + k % G;
+        }
+    }
+    const int unit = wg * 4 + wave_uniform((int)(threadIdx.x >> 6));
     if (unit >= per_frame * ws.n_frames) return;
     const int f = unit / per_frame, rem = unit % per_frame;
     const int chunk = rem / ws.frame_strips, strip = rem % ws.frame_strips;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Parses two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass on gfx950) of
-tools/traffic_driver.py into profiles/r02_traffic.json: HBM bytes per frame of the streaming kernels.
+tools/traffic_driver.py into profiles/r03_traffic.json (or the path given as third argument): HBM bytes per frame of the streaming kernels.
 
 Counter units are KiB (bytes = value * 1024).  On gfx950 the counters are only calibrated for 16-byte-per-lane streams
 (MI355X_MICROARCH.md, HBM section), so both are calibrated on `calib_copy_dword_kernel`, a copy of a known byte count
@@ -8,7 +8,7 @@ with this path's access width (one dword per lane); the correction factors are w
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/traffic_driver.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 tools/traffic_driver.py
-    python3 tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write
+    TRAFFIC_B=2048 python3 tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write [out.json]   (TRAFFIC_B as in the passes)
 """
 import csv, glob, json, os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,5 +42,6 @@ for name in ("binarise_frames_kernel", "binarise_crops_kernel"):
     out[name] = {"width": W, "height": H, "fetch_bytes_per_frame": fb, "write_bytes_per_frame": wb,
                  "hbm_bytes_per_frame": fb + wb, "raw_fetch_kib_per_launch": pick(fetch, name),
                  "raw_write_kib_per_launch": pick(write, name), "frames_per_launch": B}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_traffic.json"), "w"), indent=1)
+dest = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r03_traffic.json")
+json.dump(out, open(dest, "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -7,13 +7,14 @@ import helpers as H
 import opencv_ar_amd as oa
 B, CAL = int(os.environ.get("TRAFFIC_B", "64")), 1 << 28
 cfg = H.synth_config(3)
-frames = np.stack([H.synth_frame(cfg, i)[0] for i in range(16)] * (B // 16))
+base = np.stack([H.synth_frame(cfg, i)[0] for i in range(min(16, B))])
 tpls = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, n + ".png") for n in H.TEMPLATE_ORDER])
 cam = oa.default_camera(cfg.width, cfg.height)
 det = oa.Detector(cfg.width, cfg.height, max_batch=B)
 det.set_templates(tpls); det.set_camera(cam)
 assert oa.hip_lib().ocvar_hip_debug_calibrate(det._ctx, CAL) == 0
-d = torch.from_numpy(frames).cuda()
+d = torch.from_numpy(base).cuda().repeat((B + len(base) - 1) // len(base), 1, 1, 1)[:B].contiguous()   # tiled on the device
+torch.cuda.synchronize()
 for _ in range(4):
     det.detect_device(d.data_ptr(), cfg.width, cfg.height, B)
 print("traffic_driver: batch", B, "calibration bytes", CAL, "crop pixels/frame", det.counters()[4] / B)
