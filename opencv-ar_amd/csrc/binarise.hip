@@ -181,8 +181,9 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
             const uint2 a0 = s0[0], a1 = s0[1];       // row 2p: 16 bytes
             const uint2 b0 = s0[32], b1 = s0[33];     // row 2p+1 (one row = 64 dwords = 32 uint2)
             uint8_t* dst = o.nbr + wave_uniform64(((long long)((yr_last >> 3) * (o.ns >> 4))) << 7) + flush_dst;
-            reinterpret_cast<uint4*>(dst)[0] = make_uint4(a0.x, a0.y, a1.x, a1.y);
-            reinterpret_cast<uint4*>(dst)[1] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));   // (non-temporal stores: written once, read much later)
+            __builtin_nontemporal_store((v4u){a0.x, a0.y, a1.x, a1.y}, reinterpret_cast<v4u*>(dst));
+            __builtin_nontemporal_store((v4u){b0.x, b0.y, b1.x, b1.y}, reinterpret_cast<v4u*>(dst) + 1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     };
@@ -218,7 +219,16 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         Raw r = {0u, 0u, 0u};
         const uint8_t* row = src + wave_uniform64((long long)(inside ? v : reflect101(v, sh)) * src_stride);
         if (plan) {
-            __builtin_memcpy(&r, row + goff, BGR ? 12 : 4);   // unaligned global_load_dword / dwordx3
+            {   // one unaligned global_load_dword / dwordx3, non-temporal: the source rows stream through once and should not
+                // evict the mask lines the other contexts' border followers are walking in (+2 % with four contexts)
+                typedef unsigned __attribute__((aligned(1))) uu;
+                const uu* p = reinterpret_cast<const uu*>(row + goff);
+                r.d0 = __builtin_nontemporal_load(p);
+                if (BGR) {
+                    r.d1 = __builtin_nontemporal_load(p + 1);
+                    r.d2 = __builtin_nontemporal_load(p + 2);
+                }
+            }
             return r;
         }
         if (!needed) return r;
@@ -288,7 +298,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         if (plan && permuted) g = __builtin_amdgcn_perm(g, g, gsel);
         if (BGR && o.gray && out_lane && (S || (v >= Y0 && v < Y1))) {  // rows [Y0,Y1) are real rows, each loaded exactly once
             uint8_t* q = o.gray + wave_uniform64((long long)v * o.gray_stride) + out_off;
-            if (gray_dword) *reinterpret_cast<unsigned*>(q) = g;
+            if (gray_dword) __builtin_nontemporal_store(g, reinterpret_cast<unsigned*>(q));
             else
                 for (int j = 0; j < 4; j++)
                     if (c0 + j < sw) q[j] = (uint8_t)byte_of(g, j);
