@@ -125,6 +125,8 @@ enum { OCVAR_TUNE_CROP_PHASES = 1, /* crop-pass tier 2 in 1 launch or 2 (exact p
        OCVAR_TUNE_MID_STEPS = 2,   /* step budget of follower tier 2 before a border goes to the wave tier (>= 32) */
        OCVAR_TUNE_MID_BLOCKS = 3, OCVAR_TUNE_LONG_BLOCKS = 4, OCVAR_TUNE_SHORT_BLOCKS = 5, /* grids of tiers 2, 3, 1 */
        OCVAR_TUNE_MIN_UNITS = 6,   /* binarise work units per launch below which row chunks are not made taller */
+       OCVAR_TUNE_GATE_MODE = 8,   /* which of a context's two binarise kernels wait at its gate: 0 both (default), 1 the frames
+                                    * kernel only, 2 the crops kernel only */
        OCVAR_TUNE_HP_MASK = 7 };   /* kernels launched on the context's high-priority stream, one bit per launch: 1 tier 1
                                     * (frames), 2 tier 2, 4 tier 3, 8 order/crops, 16 tier 1 (crops), 32 tier 2, 64 tier 3,
                                     * 128 decode, 256 dedupe+pose; ocvar_hip_set_tuning(ctx, OCVAR_TUNE_HP_MASK, m) sets mask m

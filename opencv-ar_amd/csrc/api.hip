@@ -33,7 +33,7 @@ struct OcvarHip {
     int device = 0;
     OcvarGate* gate = nullptr;
     int result_limit = OCVAR_MAX_MARKERS;   // marker records per frame copied to the host (ocvar_hip_set_result_limit)
-    int tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ocvar_hip_set_tuning: 0 = default
+    int tune[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // ocvar_hip_set_tuning: 0 = default
     Workspace ws{};
     hipStream_t stream = nullptr;
     hipStream_t hp_stream = nullptr;   // high-priority stream for the kernels OCVAR_TUNE_HP_MASK names (created on first use)
@@ -269,7 +269,7 @@ extern "C" int ocvar_hip_set_camera(OcvarHip* c, const OcvarCamera* cam) {
 constexpr int HP_MASK_DEFAULT = 0;
 
 static long long tuned(const OcvarHip* c, int knob, const char* env_name, long long dflt) {
-    if (knob > 0 && knob < 8 && c->tune[knob] > 0) return knob == OCVAR_TUNE_HP_MASK ? c->tune[knob] - 1 : c->tune[knob];
+    if (knob > 0 && knob < 12 && c->tune[knob] > 0) return knob == OCVAR_TUNE_HP_MASK ? c->tune[knob] - 1 : c->tune[knob];
 #ifdef OCVAR_PROF
     if (const char* e = std::getenv(env_name)) return std::atoll(e);
 #else
@@ -279,7 +279,7 @@ static long long tuned(const OcvarHip* c, int knob, const char* env_name, long l
 }
 
 extern "C" int ocvar_hip_set_tuning(OcvarHip* c, int knob, int value) {
-    if (!c || knob < 1 || knob > 7 || value < 0 || c->pending) return OCVAR_E_ARG;
+    if (!c || knob < 1 || knob > 8 || value < 0 || c->pending) return OCVAR_E_ARG;
     c->tune[knob] = knob == OCVAR_TUNE_HP_MASK ? value + 1 : value;   // (0 is a meaningful mask: stored off by one, 0 = default)
     return OCVAR_OK;
 }
@@ -413,10 +413,11 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
         cur = to;
         return e;
     };
-    HIP_TRY(c, gate_enter(c->gate, s));   // (before the first timing event: a wait at the gate is not binarise time)
+    const int gate_mode = (int)tuned(c, OCVAR_TUNE_GATE_MODE, "OCVAR_GATE_MODE", 0);   // which binarise kernels the gate covers: 0 both, 1 the frames kernel only, 2 the crops kernel only
+    if (gate_mode != 2) HIP_TRY(c, gate_enter(c->gate, s));   // (before the first timing event: a wait at the gate is not binarise time)
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     launch_binarise_frames(w, d_bgr, row_stride, frame_stride, grey_in_place, s);
-    HIP_TRY(c, gate_leave(c->gate, s));
+    if (gate_mode != 2) HIP_TRY(c, gate_leave(c->gate, s));
     TRACE_LAUNCH("binarise_frames", s);
     // Timing experiments (results are then incomplete or wrong): compiled into profiling builds only (-DOCVAR_PROF, `make prof`)
     //   OCVAR_ONLY_BINARISE=1        stop after the first kernel (tools/binarise_only.py)
@@ -453,10 +454,10 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     if (stages > 2) {
         // (the gate wait is enqueued on s before s is made to wait for the order kernel: a wait here is booked under the
         // order_crops interval)
-        HIP_TRY(c, gate_enter(c->gate, s));
+        if (gate_mode != 1) HIP_TRY(c, gate_enter(c->gate, s));
         HIP_TRY(c, stage(5, -1));
         if (!(skip_crop & 1)) launch_binarise_crops(w, s);
-        HIP_TRY(c, gate_leave(c->gate, s));
+        if (gate_mode != 1) HIP_TRY(c, gate_leave(c->gate, s));
         TRACE_LAUNCH("binarise_crops", s);
         HIP_TRY(c, stage(6, 4));
         if (!(skip_crop & 2)) launch_follow_crops(w, cur);
