@@ -184,6 +184,10 @@ def main():
     # sub-batches; the host only ever waits for the context whose launch is oldest.
     stage_full = np.zeros(12, np.float64)   # per-kernel event times of full-size launches inside the timed region
     n_full = [0]
+    ref_event = torch.cuda.Event(enable_timing=True)   # one clock for the stage stamps of all contexts
+    ref_event.record()
+    ref_event.synchronize()
+    spans = {0: [], 5: []}   # (start, end) in ms after ref_event of every full-size launch of the two binarise kernels (timed region)
     frames_done = [0]
     last = {}
 
@@ -212,6 +216,9 @@ def main():
         if timed and last[i] == sub[i]:
             stage_full[:] += dets[i].stage_ms()
             n_full[0] += 1
+            st = dets[i].stage_stamps(ref_event.cuda_event)
+            for k in spans:
+                spans[k].append((float(st[k]), float(st[k + 1])))
         return m, c
 
     def run(K, timed):
@@ -299,7 +306,28 @@ def main():
         # byte figure is nominal; with several contexts in flight their launches are the ones the GPU time-slices, so their
         # launch durations say how the contexts share the GPU, not what the kernels do)
         dom = max(kernels, key=lambda k: k[2])
-        ach = dom[2] / (stage_ms[dom[1]] * 1e-3) / 1e9
+        # `roofline` is the contract's figure: algorithmic bytes per launch / the kernel's mean launch duration (HIP events on
+        # its stream, timed region; agrees with the rocprofv3 --stats average of the same command).  The contexts' launches of
+        # this kernel overlap each other, though (the gate lets two binarise kernels run at once), and a launch's own duration
+        # counts the time it shared with another launch of the SAME kernel twice.  `while_running` therefore adds what the
+        # kernel moved while it was on the GPU at all: the bytes of all its launches over the union of their [start, end]
+        # intervals (all contexts' events on one clock, ocvar_hip_stage_stamps).  Time shared with OTHER kernels stays in both.
+        def union_ms(iv):
+            iv = sorted(iv)
+            tot, cur_a, cur_b = 0.0, None, None
+            for a, b in iv:
+                if cur_b is None or a > cur_b:
+                    if cur_b is not None:
+                        tot += cur_b - cur_a
+                    cur_a, cur_b = a, b
+                else:
+                    cur_b = max(cur_b, b)
+            return tot + ((cur_b - cur_a) if cur_b is not None else 0.0)
+        iv = spans.get(dom[1], [])
+        busy_ms = union_ms(iv) if iv else stage_ms[dom[1]] * max(1, n_full[0])
+        excl_ms = busy_ms / max(1, len(iv))        # per launch, overlap with launches of the same kernel shared out
+        ach = dom[2] / (stage_ms[dom[1]] * 1e-3) / 1e9      # the contract's figure: bytes per launch / mean launch duration
+        ach_busy = dom[2] / (excl_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if os.path.exists(tf):   # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this launch size (tools/collect_traffic.py)
@@ -317,7 +345,11 @@ def main():
                        "parallelism": f"frame-sharded x{world}" + ((f", RCCL gather of CvarMarker arrays ({GATHER_K} records per frame + counts)" if backend == "nccl" else f", {backend} rehearsal of the gather (ranks share devices)") if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "launch_ms": round(float(stage_ms[dom[1]]), 4), "alg_bytes_per_launch": round(dom[2])},
+                         "launch_ms": round(float(stage_ms[dom[1]]), 4), "alg_bytes_per_launch": round(dom[2]),
+                         "while_running": {"launches": len(iv), "kernel_on_gpu_ms": round(float(busy_ms), 3), "ms_per_launch": round(float(excl_ms), 4),
+                                           "achieved": round(ach_busy, 2), "frac": round(ach_busy / HBM_PEAK_GBS, 5),
+                                           "note": "bytes of all full-size launches of this kernel in the timed region / time at least one of them was running "
+                                                   "(the contexts' launches overlap each other: launch_ms counts time two of them ran side by side twice)"}},
             "pipeline_roofline": {"bound": "hbm", "achieved": round(alg_frame * fps / world / 1e9, 2), "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": round(alg_frame * fps / world / 1e9 / HBM_PEAK_GBS, 5),
                                   "alg_bytes_per_frame": round(alg_frame)},

@@ -190,6 +190,10 @@ int ocvar_hip_debug_calibrate(OcvarHip* ctx, size_t bytes);
  * [0] binarise(frames) [1..3] follower tiers 1,2,3 (frames) [4] order/crops [5] binarise(crops)
  * [6..8] follower tiers 1,2,3 (crops) [9] decode [10] dedupe+pose [11] whole batch.  Returns the number written. */
 int ocvar_hip_stage_ms(OcvarHip* ctx, float* ms, int n);
+/* The same 13 stage boundaries ([0] start of binarise(frames) ... [12] end of the copy-out) as milliseconds after ref_event, a
+ * hipEvent_t the caller recorded (with timing) on this device before enqueueing: stamps of different contexts are on one clock,
+ * so a caller with several contexts in flight can tell how launches of one kernel overlapped.  Returns the number written. */
+int ocvar_hip_stage_stamps(OcvarHip* ctx, void* ref_event, float* ms, int n);
 /* Work counters of the last batch: [0] frame start candidates [1] crop ROIs [2] crop tiles
  * [3] crop start candidates [4] sum of crop areas (pixels) [5] point-pool ints used [6],[7] starts handed to follower
  * tier 2 (frames, crops) [8],[9] borders handed to tier 3 (frames, crops) [10]..[41] profiling slots of builds made with

@@ -44,6 +44,8 @@ struct OcvarHip {
     size_t d_frames_bytes = 0;
     uint8_t* h_stage[2] = {nullptr, nullptr};   // page-locked staging of the host entry points (double buffer)
     size_t h_stage_bytes = 0;                   // size of each
+    uint8_t* h_grey[2] = {nullptr, nullptr};    // page-locked staging of the in-place grey on its way back (double buffer)
+    size_t h_grey_bytes = 0;
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;   // host transport of ocvar_hip_detect_host (created on first use)
     std::vector<hipEvent_t> h2d_done;
     hipEvent_t computed = nullptr;
@@ -177,6 +179,8 @@ extern "C" void ocvar_hip_destroy(OcvarHip* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->d_frames) (void)hipFree(c->d_frames);
     for (auto p : c->h_stage)
+        if (p) (void)hipHostFree(p);
+    for (auto p : c->h_grey)
         if (p) (void)hipHostFree(p);
     if (c->h_markers) (void)hipHostFree(c->h_markers);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -613,6 +617,19 @@ static int reserve_host_stage(OcvarHip* c, size_t bytes) {
     return OCVAR_OK;
 }
 
+static int reserve_host_grey(OcvarHip* c, size_t bytes) {
+    if (bytes > c->h_grey_bytes) {
+        for (auto& p : c->h_grey) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+        }
+        c->h_grey_bytes = 0;
+        for (auto& p : c->h_grey) HIP_TRY(c, hipHostMalloc((void**)&p, bytes));
+        c->h_grey_bytes = bytes;
+    }
+    return OCVAR_OK;
+}
+
 static int stage_frames(OcvarHip* c, const uint8_t* h, int height, int row_stride, size_t frame_stride, int n_frames) {
     const size_t bytes = (size_t)(n_frames - 1) * frame_stride + (size_t)height * row_stride;
     int rc = reserve_staging(c, bytes);
@@ -690,6 +707,7 @@ extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int
     if (rc) return rc;
     const size_t slot_bytes = (span_max + 255) & ~(size_t)255;
     if (!direct && (rc = reserve_host_stage(c, span_max))) return rc;
+    if (!direct && grey_in_place && (rc = reserve_host_grey(c, span_max))) return rc;
     if (!c->h2d_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
     if (!c->d2h_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
     while (c->h2d_done.size() < 2) {
@@ -698,10 +716,12 @@ extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int
         c->h2d_done.push_back(ev);
     }
     // On any failure: nothing of this call may still be in flight when it returns (the staging buffers are reused by the next)
+    std::thread* copier_ref = nullptr;   // (set once the helper thread exists: fail() must not leave it running)
     auto fail = [&](int code) {
         (void)hipStreamSynchronize(c->h2d_stream);
         (void)hipStreamSynchronize(c->d2h_stream);
         (void)hipStreamSynchronize(c->stream);
+        if (copier_ref && copier_ref->joinable()) copier_ref->join();
         c->pending = false;
         return code;
     };
@@ -727,13 +747,21 @@ extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int
         if (e == hipSuccess) e = hipEventRecord(c->h2d_done[k & 1], c->h2d_stream);
         return e;
     };
-    auto grey_home = [&](int k) -> hipError_t {   // the grey frames of sub-batch k, already on their way, into the caller's buffer
+    // the grey frames of sub-batch k, already on their way: wait for the copy engine, then a helper thread copies them from the
+    // staging buffer into the caller's frames while this thread stages the next upload (different buffers)
+    std::thread grey_copier;
+    copier_ref = &grey_copier;
+    auto grey_join = [&] { if (grey_copier.joinable()) grey_copier.join(); };
+    auto grey_home = [&](int k) -> hipError_t {
         const hipError_t e = hipStreamSynchronize(c->d2h_stream);
         if (e != hipSuccess || direct) return e;
         size_t off;
         int cnt;
         const size_t len = span(k, &off, &cnt);
-        host_copy(h_bgr + off, c->h_stage[k & 1], len);
+        grey_join();
+        uint8_t* dst = h_bgr + off;
+        const uint8_t* src = c->h_grey[k & 1];
+        grey_copier = std::thread([=] { host_copy(dst, src, len); });
         return hipSuccess;
     };
     HIP_TRY_HOST(upload(0));
@@ -752,9 +780,11 @@ extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int
         rc = ocvar_hip_collect(c, markers ? markers + (size_t)k * sub * max_per_frame : nullptr, counts + k * sub, max_per_frame);
         if (rc) return fail(rc);
         if (grey_in_place)   // (the kernels of sub-batch k have finished: collect waited for them)
-            HIP_TRY_HOST(hipMemcpyAsync(direct ? h_bgr + off : c->h_stage[k & 1], d_slot, len, hipMemcpyDeviceToHost, c->d2h_stream));
+            // (slot k & 1 last held sub-batch k - 2, whose copy-back thread was joined when sub-batch k - 1's was started)
+            HIP_TRY_HOST(hipMemcpyAsync(direct ? h_bgr + off : c->h_grey[k & 1], d_slot, len, hipMemcpyDeviceToHost, c->d2h_stream));
     }
     if (grey_in_place) HIP_TRY_HOST(grey_home(n_sub - 1));
+    grey_join();
 #undef HIP_TRY_HOST
     return OCVAR_OK;
 }
@@ -861,6 +891,20 @@ extern "C" int ocvar_hip_stage_ms(OcvarHip* c, float* ms, int n) {
         if (hipEventElapsedTime(&ms[11], c->ev[0], c->ev[12]) != hipSuccess) ms[11] = -1.f;
         k = 12;
     }
+    return k;
+}
+
+// Where the last batch's 13 stage events lie on the device's clock, in milliseconds after the caller's reference event
+// (recorded on any stream of this device before the batch was enqueued).  With several contexts in flight the launches of one
+// kernel overlap each other; their start/end stamps let a caller compute how long the GPU was running that kernel at all.
+extern "C" int ocvar_hip_stage_stamps(OcvarHip* c, void* ref_event, float* ms, int n) {
+    if (!c || !ref_event || !ms || n < 1 || c->pending) return OCVAR_E_ARG;
+    int k = 0;
+    for (; k < 13 && k < n; k++)
+        if (hipEventElapsedTime(&ms[k], (hipEvent_t)ref_event, c->ev[k]) != hipSuccess) {
+            (void)hipGetLastError();
+            ms[k] = -1.f;
+        }
     return k;
 }
 

@@ -219,15 +219,15 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         Raw r = {0u, 0u, 0u};
         const uint8_t* row = src + wave_uniform64((long long)(inside ? v : reflect101(v, sh)) * src_stride);
         if (plan) {
-            {   // one unaligned global_load_dword / dwordx3, non-temporal: the source rows stream through once and should not
-                // evict the mask lines the other contexts' border followers are walking in (+2 % with four contexts)
+            if (BGR) {   // one unaligned global_load_dwordx3, non-temporal: a frame's rows stream through once and should not evict
+                         // the mask lines the other contexts' border followers are walking in (+2 % with four contexts)
                 typedef unsigned __attribute__((aligned(1))) uu;
                 const uu* p = reinterpret_cast<const uu*>(row + goff);
                 r.d0 = __builtin_nontemporal_load(p);
-                if (BGR) {
-                    r.d1 = __builtin_nontemporal_load(p + 1);
-                    r.d2 = __builtin_nontemporal_load(p + 2);
-                }
+                r.d1 = __builtin_nontemporal_load(p + 1);
+                r.d2 = __builtin_nontemporal_load(p + 2);
+            } else {     // crops: ordinary loads -- the two concentric quads of a marker give two crops over nearly the same pixels
+                __builtin_memcpy(&r, row + goff, 4);
             }
             return r;
         }

@@ -43,3 +43,21 @@ for (bb, ff, tt), v in hist.items():
 print("binarise kernels running at once:", {k: "%.1f %%" % (100 * v / tot) for k, v in sorted(nb.items())})
 print("kernels of any kind running at once:", {k: "%.1f %%" % (100 * v / tot) for k, v in sorted(nk.items())})
 print("most frequent (binarise, followers, tail) states:", [(k, "%.1f %%" % (100 * v / tot)) for k, v in sorted(hist.items(), key=lambda kv: -kv[1])[:6]])
+
+# the figure bench.py reports as roofline.launch_ms: time at least one binarise_frames_kernel was running, per launch
+for name in ("binarise_frames_kernel", "binarise_crops_kernel"):
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if name in r["Kernel_Name"] and a <= int(r["Start_Timestamp"]) <= b)
+    # full-size launches only (the pipeline's first and last launches are partial): within 25 % of the median duration... by grid size if present
+    if not iv:
+        continue
+    tot, ca, cb = 0, None, None
+    for x, y in iv:
+        if cb is None or x > cb:
+            if cb is not None:
+                tot += cb - ca
+            ca, cb = x, y
+        else:
+            cb = max(cb, y)
+    tot += cb - ca
+    mean = sum(y - x for x, y in iv) / len(iv)
+    print(f"{name}: {len(iv)} launches in the window, mean start-to-end {mean / 1e6:.3f} ms, time at least one was running per launch {tot / len(iv) / 1e6:.3f} ms")

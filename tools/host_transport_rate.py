@@ -14,11 +14,15 @@ tpls = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, n + ".png") for n in H.T
 cam = oa.default_camera(cfg.width, cfg.height)
 det = oa.Detector(cfg.width, cfg.height, max_batch=64)
 det.set_templates(tpls); det.set_camera(cam)
-for grey in (False, True):
-    det.detect_host(frames.copy(), grey_in_place=grey)
-    work = frames.copy()
-    t0 = time.perf_counter()
-    m, c = det.detect_host(work, grey_in_place=grey)
-    dt = time.perf_counter() - t0
-    print(f"detect_host {B} frames 1920x1080, grey_in_place={grey}: {B / dt:.0f} frames/s, {B * frames[0].nbytes / dt / 1e9:.1f} GB/s host->device"
-          f"{' + back' if grey else ''}, markers/frame {c.mean():.2f}")
+import torch
+pinned = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True).numpy()   # hipHostMalloc: page-locked by the CALLER
+for label, make in (("pageable buffer (staged through the library's page-locked buffers)", lambda: frames.copy()),
+                    ("buffer page-locked by the caller (used in place)", lambda: (pinned.__setitem__(slice(None), frames), pinned)[1])):
+    for grey in (False, True):
+        det.detect_host(make(), grey_in_place=grey)
+        work = make()
+        t0 = time.perf_counter()
+        m, c = det.detect_host(work, grey_in_place=grey)
+        dt = time.perf_counter() - t0
+        print(f"detect_host {B} frames 1920x1080, {label}, grey_in_place={grey}: {B / dt:.0f} frames/s, {B * frames[0].nbytes / dt / 1e9:.1f} GB/s host->device"
+              f"{' + back' if grey else ''}, markers/frame {c.mean():.2f}")
