@@ -127,7 +127,6 @@ enum { OCVAR_TUNE_CROP_PHASES = 1, /* crop-pass tier 2 in 1 launch or 2 (exact p
        OCVAR_TUNE_MIN_UNITS = 6,   /* binarise work units per launch below which row chunks are not made taller */
        OCVAR_TUNE_GATE_MODE = 8,   /* which of a context's two binarise kernels wait at its gate: 0 both (default), 1 the frames
                                     * kernel only, 2 the crops kernel only */
-       OCVAR_TUNE_CROP_LDS = 9,    /* 1: the crop pass's tier 2 walks from bit images in LDS (crop_walk_kernel), 2: from the byte planes */
        OCVAR_TUNE_HP_MASK = 7 };   /* kernels launched on the context's high-priority stream, one bit per launch: 1 tier 1
                                     * (frames), 2 tier 2, 4 tier 3, 8 order/crops, 16 tier 1 (crops), 32 tier 2, 64 tier 3,
                                     * 128 decode, 256 dedupe+pose; ocvar_hip_set_tuning(ctx, OCVAR_TUNE_HP_MASK, m) sets mask m

@@ -324,7 +324,7 @@ class Detector:
         """marker records per frame a batch brings to the host (default MAX_MARKERS); counts stay the full counts"""
         self._check(self._lib.ocvar_hip_set_result_limit(self._ctx, max_per_frame), "set_result_limit")
 
-    TUNE = {"crop_phases": 1, "mid_steps": 2, "mid_blocks": 3, "long_blocks": 4, "short_blocks": 5, "min_units": 6, "hp_mask": 7, "gate_mode": 8, "crop_lds": 9}
+    TUNE = {"crop_phases": 1, "mid_steps": 2, "mid_blocks": 3, "long_blocks": 4, "short_blocks": 5, "min_units": 6, "hp_mask": 7, "gate_mode": 8}
 
     def set_tuning(self, **kw):
         """result-invariant launch parameters (include/ocvar_hip.h: OCVAR_TUNE_*); 0 restores a default"""

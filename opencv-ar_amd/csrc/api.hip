@@ -36,8 +36,7 @@ struct OcvarHip {
     int tune[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // ocvar_hip_set_tuning: 0 = default
     Workspace ws{};
     hipStream_t stream = nullptr;
-    hipStream_t hp_stream = nullptr;   // high- (or low-) priority stream for the kernels OCVAR_TUNE_HP_MASK names (created on first use)
-    bool hp_is_low = false;
+    hipStream_t hp_stream = nullptr;   // high-priority stream for the kernels OCVAR_TUNE_HP_MASK names (created on first use)
     hipStream_t last_stream = nullptr;
     hipEvent_t ev[13]{};   // 12 intervals: see ocvar_hip_stage_ms
     std::vector<void*> allocs;
@@ -150,10 +149,6 @@ extern "C" int ocvar_hip_create_ex(OcvarHip** out, int device, int max_width, in
     if ((rc = dev_alloc(c, &w.quads_crop, (size_t)w.cap_crop_quads))) return rc;
     if ((rc = dev_alloc(c, &w.best_crop, (size_t)w.cap_crop_rois))) return rc;
     if ((rc = dev_alloc(c, &w.crop_min_rest, (size_t)w.cap_crop_rois))) return rc;
-    if ((rc = dev_alloc(c, &w.crop_starts, (size_t)w.cap_crop_rois * CS_CAP))) return rc;
-    if ((rc = dev_alloc(c, &w.crop_nstarts, (size_t)w.cap_crop_rois))) return rc;
-    w.cap_fin = w.cap_long;
-    if ((rc = dev_alloc(c, &w.fin_crop, (size_t)w.cap_fin))) return rc;
     if ((rc = dev_alloc(c, &w.cand_recs, B * max_quads * MAXT))) return rc;
     if ((rc = dev_alloc(c, &w.prev, B * MAXM))) return rc;
     if ((rc = dev_alloc(c, &w.n_prev, B))) return rc;
@@ -288,7 +283,7 @@ static long long tuned(const OcvarHip* c, int knob, const char* env_name, long l
 }
 
 extern "C" int ocvar_hip_set_tuning(OcvarHip* c, int knob, int value) {
-    if (!c || knob < 1 || knob > 9 || value < 0 || c->pending) return OCVAR_E_ARG;
+    if (!c || knob < 1 || knob > 8 || value < 0 || c->pending) return OCVAR_E_ARG;
     c->tune[knob] = knob == OCVAR_TUNE_HP_MASK ? value + 1 : value;   // (0 is a meaningful mask: stored off by one, 0 = default)
     return OCVAR_OK;
 }
@@ -364,10 +359,6 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     // thousands of workgroups that keep a 2048-frame batch busy
     w.short_blocks = tuned(c, OCVAR_TUNE_SHORT_BLOCKS, "OCVAR_SHORT_BLOCKS", n_frames >= 128 ? 1024 : (n_frames * 8 < 16 ? 16 : n_frames * 8));
     if (w.short_blocks < 1 || w.short_blocks > 65535) w.short_blocks = 1024;
-    // the crop walker (bit images in LDS) takes the crop pass's tier 2 for batches; a few frames keep the one-launch walk from the byte planes
-    w.crop_lds = (int)tuned(c, OCVAR_TUNE_CROP_LDS, "OCVAR_CROP_LDS", 0) == 1 && n_frames > 8 ? 1 : 0;
-    w.fin_blocks = n_frames >= 128 ? 4096 : (n_frames * 32 < 64 ? 64 : n_frames * 32);    // (one-wave workgroups)
-    w.walk_blocks = n_frames >= 128 ? 2048 : (n_frames * 16 < 32 ? 32 : n_frames * 16);
     w.crop_blocks = n_frames >= 128 ? 2048 : (n_frames * 16 < 32 ? 32 : n_frames * 16);
     w.frame_strips = (w.sw + MARCH_STRIP - 1) / MARCH_STRIP;
     {   // rows per binarise work unit: even, chunks of equal size.  Every chunk re-reads ~12 halo rows, so chunks are as
@@ -412,19 +403,11 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     // first.  (All followers on the high-priority stream -- round 2's OCVAR_SPLIT_STREAMS -- halved their in-region durations and
     // lengthened binarise's by as much; the mask chooses kernel by kernel.)  The events that time the stages also order the
     // streams.
-    const int hp_raw = (int)tuned(c, OCVAR_TUNE_HP_MASK, "OCVAR_HP_MASK", HP_MASK_DEFAULT);
-    const int hp_mask = hp_raw & 0x1ff;
-    const bool want_low = (hp_raw & 0x200) != 0;   // + 512: the masked kernels go to a LOW-priority stream instead (binarise outranks them)
-    if (hp_mask && (!c->hp_stream || c->hp_is_low != want_low)) {
-        if (c->hp_stream) {
-            (void)hipStreamSynchronize(c->hp_stream);
-            (void)hipStreamDestroy(c->hp_stream);
-            c->hp_stream = nullptr;
-        }
+    const int hp_mask = (int)tuned(c, OCVAR_TUNE_HP_MASK, "OCVAR_HP_MASK", HP_MASK_DEFAULT) & 0x1ff;
+    if (hp_mask && !c->hp_stream) {
         int lo = 0, hi = 0;
         HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi: numerically lowest = greatest priority
-        HIP_TRY(c, hipStreamCreateWithPriority(&c->hp_stream, hipStreamNonBlocking, want_low ? lo : hi));
-        c->hp_is_low = want_low;
+        HIP_TRY(c, hipStreamCreateWithPriority(&c->hp_stream, hipStreamNonBlocking, hi));
     }
     hipStream_t cur = s;   // the stream the chain is on
     auto stage = [&](int k, int bit) -> hipError_t {   // timing event k at the end of the previous stage; the next one runs where its bit says

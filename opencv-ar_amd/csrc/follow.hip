@@ -618,19 +618,7 @@ __global__ __launch_bounds__(FOLLOW_THREADS) void follow_kernel(Workspace ws) {
             route = follow_short<CROP>(ws, c);
         }
         queued -= take;
-        if (CROP && ws.crop_lds) {
-            // crop walker: a crop's surviving starts go to the crop's own array (one atomic on the crop's own counter); a crop with
-            // more than CS_CAP of them sends the rest to the tier-2 lists, which follow_mid_kernel still drains
-            if (route == 1 || route == 3) {
-                const int k = atomicAdd(ws.crop_nstarts + c.roi, 1);
-                if (k < CS_CAP) {
-                    ws.crop_starts[(size_t)c.roi * CS_CAP + k] = (unsigned)c.pos | (route == 3 ? 1u << 30 : 0u) | ((unsigned)c.is_hole << 31);
-                    route = 0;
-                }
-            }
-        } else if (CROP && route == 1) {
-            atomicMin(ws.crop_min_rest + c.roi, c.pos);   // tier 2 walks a crop's earliest start first (see follow_mid_kernel)
-        }
+        if (CROP && route == 1) atomicMin(ws.crop_min_rest + c.roi, c.pos);   // tier 2 walks a crop's earliest start first (see follow_mid_kernel)
         collect(0, o_n0, route == 1, c);
         collect(1, o_n1, route == 2, c);
         if (CROP) collect(2, o_n2, route == 3, c);
@@ -951,351 +939,6 @@ __global__ __launch_bounds__(FOLLOW_THREADS) void follow_mid_kernel(Workspace ws
     PROF_FLUSH(CROP ? 16 : 0);
 }
 
-// ---- Crop walker: the crop pass's tier 2 from bit images in LDS ---------------------------------------------------------------
-// With 2048 frames per launch the crops' mask planes (2.5 GB) fit no cache: every tile a walk enters is a 128-byte read from
-// HBM at a random address for the sake of ~2 of its bytes -- 160 M steps, 43 % L1 misses: 8.8 GB of such reads per batch, next to the
-// 30 GB the two binarise kernels stream.  A crop's BINARY image is 4 - 5 KB as bits.  Here a wave packs the bit images of as many
-// consecutive crops as fit into its LDS arena (one coalesced pass over their mask planes, bit 4 -- "west neighbour is set" -- of
-// every mask byte: the binary image shifted right by one pixel), takes those crops' surviving starts from the crops' own arrays
-// (tier 1 files them there) and walks them, one lane per start, with the 8-neighbour mask of a pixel assembled from three LDS
-// reads and a 512-entry table.  A step costs LDS latency instead of a DRAM round trip, so few lanes in flight suffice, and the
-// memory system sees each mask plane once.  No phases: all of a crop's starts are walked in one launch (steps are cheap now),
-// closed borders are published to the point pool and approximated by follow_finish_kernel, one wave per border; "the crop's
-// earliest quad wins" is the atomicMin in emit_quad.  Borders that outrun the step budget or a slab go to the wave tier as before.
-constexpr int CW_ARENA = 26 * 1024;          // bytes of bit images per wave
-constexpr int CW_MAXG = 10;                  // crops per group
-constexpr int CW_QCAP = CW_MAXG * CS_CAP;    // starts of a group
-
-__device__ __forceinline__ unsigned lds_mask(const uint8_t* img, unsigned rs, unsigned x, unsigned y, const uint8_t* lut) {
-    // binary(x + dx, y + dy) = bit x + dx + 1 of row y + dy of the shifted image: bits x .. x + 2 of rows y - 1, y, y + 1
-    const uint8_t* p = img + (y - 1u) * rs + ((x >> 5) << 2);
-    const unsigned sh = x & 31u;
-    const unsigned* qa = reinterpret_cast<const unsigned*>(p);        // two dwords per row (4-byte aligned: ds_read2_b32)
-    const unsigned* qm = reinterpret_cast<const unsigned*>(p + rs);
-    const unsigned* qb = reinterpret_cast<const unsigned*>(p + 2u * rs);
-    const unsigned ia = __builtin_amdgcn_alignbit(qa[1], qa[0], sh) & 7u;
-    const unsigned im = __builtin_amdgcn_alignbit(qm[1], qm[0], sh) & 7u;
-    const unsigned ib = __builtin_amdgcn_alignbit(qb[1], qb[0], sh) & 7u;
-    return lut[ia | (im << 3) | (ib << 6)];
-}
-
-// 3 x 3 neighbourhood (row above | own row << 3 | row below << 6, west pixel in the low bit) -> the follower's mask
-// (bit s = neighbour in direction s = E NE N NW W SW S SE is set)
-__device__ __forceinline__ unsigned lut_entry(unsigned idx) {
-    const unsigned nw = idx & 1u, n = (idx >> 1) & 1u, ne = (idx >> 2) & 1u, w = (idx >> 3) & 1u, e = (idx >> 5) & 1u;
-    const unsigned sw = (idx >> 6) & 1u, so = (idx >> 7) & 1u, se = (idx >> 8) & 1u;
-    return e | (ne << 1) | (n << 2) | (nw << 3) | (w << 4) | (sw << 5) | (so << 6) | (se << 7);
-}
-
-__global__ __launch_bounds__(64) void crop_walk_kernel(Workspace ws) {
-    __shared__ __attribute__((aligned(16))) uint8_t arena[CW_ARENA + 32];
-    __shared__ unsigned parked[64 * POINT_ROW];
-    __shared__ unsigned step_tab[64];
-    __shared__ __attribute__((aligned(4))) uint8_t nb_lut[512];
-    __shared__ unsigned q_start[CW_QCAP];   // pos | is_hole << 31 (flag bit 30 dropped)
-    __shared__ uint8_t q_slot[CW_QCAP];
-    __shared__ int g_roi[CW_MAXG], g_img[CW_MAXG], g_rs[CW_MAXG], g_ns[CW_MAXG];
-    const int lane = threadIdx.x;
-    step_tab[lane] = lean_table_entry((unsigned)lane);
-    for (int i = lane; i < 512; i += 64) nb_lut[i] = (uint8_t)lut_entry((unsigned)i);
-    __syncthreads();
-    int n_crops = uni(ws.counters[CNT_CROP_ROIS]);
-    if (n_crops > ws.cap_crop_rois) n_crops = ws.cap_crop_rois;
-    // every wave owns a contiguous run of crops (consecutive crops are neighbours in a frame) and goes through it group by group
-    const int per = (n_crops + (int)gridDim.x - 1) / (int)gridDim.x;
-    int next = (int)blockIdx.x * per;
-    const int end = next + per < n_crops ? next + per : n_crops;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    unsigned* wave_slabs = reinterpret_cast<unsigned*>(ws.slab) + (size_t)blockIdx.x * 64 * SLAB_STRIDE;   // (grid <= slabs / 64: launch_follow_mid_crops)
-    unsigned* my_row = parked + lane * POINT_ROW;
-    const int budget = ws.mid_steps;
-    for (int guard_g = per + 2; next < end; guard_g--) {
-        if (guard_g < 0) {
-            if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TICKET_RUNAWAY);
-            break;
-        }
-        // ---- the group: consecutive crops while their bit images fit the arena ----
-        int G = 0, used = 0, q_n = 0;
-        while (G < CW_MAXG && next < end) {
-            Roi r = ws.rois_crop[next];
-            r.ns = uni(r.ns);
-            r.sh = uni(r.sh);
-            r.nbr_off = (long long)uni((unsigned long long)r.nbr_off);
-            const int rs = 4 * ((r.ns >> 5) + 2);                 // bytes per image row: ns + 1 bits and the word the 64-bit reads touch behind them
-            const int bytes = (rs * (r.sh + 1) + 15) & ~15;       // (+ one row: the row below the last one is read, as zeros)
-            if (bytes > CW_ARENA) {
-                // a crop larger than the arena (a marker that fills a 4K frame): its starts go back to the tier-2 lists
-                int ns_ = uni(ws.crop_nstarts[next]);
-                ns_ = ns_ < CS_CAP ? ns_ : CS_CAP;
-                if (G == 0) {
-                    if (lane < ns_) {
-                        const unsigned e = ws.crop_starts[(size_t)next * CS_CAP + lane];
-                        StartCand c;
-                        c.roi = next; c.pos = (int)(e & 0x3fffffffu); c.is_hole = (int)(e >> 31);
-                        const int slot = atomicAdd(ws.counters + CNT_MID_C, 1);
-                        if (slot < ws.cap_long) ws.mid_crop[slot] = c;
-                        else atomicOr(ws.counters + CNT_ERR, ERR_CAND_OVERFLOW);
-                    }
-                    next++;
-                    continue;
-                }
-                break;   // finish the group in hand first
-            }
-            if (used + bytes > CW_ARENA) break;
-            // bit image: one tile row (16 mask bytes) per lane and pass -> 16 bits
-            uint8_t* img = arena + used;
-            for (int i = lane * 4; i < bytes; i += 256) *reinterpret_cast<unsigned*>(img + i) = 0u;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            const uint8_t* plane = ws.nbr_crop + r.nbr_off;
-            const int tiles_x = r.ns >> 4, n_rows = tiles_x * r.sh;
-            for (int t0 = 0; t0 < n_rows; t0 += 64 * 4) {
-                uint4 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int t = t0 + lane + 64 * u;
-                    v[u] = make_uint4(0u, 0u, 0u, 0u);
-                    if (t < n_rows) {
-                        const int y = t / tiles_x, tx = t - y * tiles_x;
-                        v[u] = *reinterpret_cast<const uint4*>(plane + nbr_addr(tx << 4, y, r.ns));
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int t = t0 + lane + 64 * u;
-                    if (t < n_rows) {
-                        const int y = t / tiles_x, tx = t - y * tiles_x;
-                        // bit 4 of every byte, packed: ((d >> 4) & 0x01010101) * 0x01020408 >> 24 puts byte k's bit at bit k
-                        const unsigned b0 = ((((v[u].x >> 4) & 0x01010101u) * 0x01020408u) >> 24) & 15u;
-                        const unsigned b1 = ((((v[u].y >> 4) & 0x01010101u) * 0x01020408u) >> 24) & 15u;
-                        const unsigned b2 = ((((v[u].z >> 4) & 0x01010101u) * 0x01020408u) >> 24) & 15u;
-                        const unsigned b3 = ((((v[u].w >> 4) & 0x01010101u) * 0x01020408u) >> 24) & 15u;
-                        *reinterpret_cast<unsigned short*>(img + y * rs + tx * 2) = (unsigned short)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12));
-                    }
-                }
-            }
-            // its starts
-            int ns_ = uni(ws.crop_nstarts[next]);
-            ns_ = ns_ < CS_CAP ? ns_ : CS_CAP;
-            if (lane < ns_) {
-                q_start[q_n + lane] = ws.crop_starts[(size_t)next * CS_CAP + lane] & 0xbfffffffu;
-                q_slot[q_n + lane] = (uint8_t)G;
-            }
-            if (lane == 0) {
-                g_roi[G] = next;
-                g_img[G] = used;
-                g_rs[G] = rs;
-                g_ns[G] = r.ns;
-            }
-            q_n += ns_;
-            used += bytes;
-            G++;
-            next++;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        if (q_n == 0) continue;
-        // ---- walk the group's starts: lanes take them from the queue as they fall idle ----
-        int q_next = 0;          // wave-uniform
-        bool have = false;
-        int flushed = 0;
-        StartCand c;
-        c.roi = 0; c.pos = 0; c.is_hole = 0;
-        LeanWalk w;
-        w.xy = w.m = w.from = w.pe = w.xy0 = w.xy1 = w.cxy = 0u;
-        w.npts = w.step = 0;
-        w.status = TRACE_NOT_FIRST;
-        const uint8_t* img = arena;
-        unsigned rs = 8u;
-        for (long long guard = (long long)(q_n + 64) * (budget / MID_BLOCK + 5) + 64;; guard--) {
-            if (guard < 0) {
-                if (lane == 0) atomicOr(ws.counters + CNT_ERR, ERR_TICKET_RUNAWAY);
-                break;
-            }
-            {
-                const unsigned long long idle = __ballot(!have);
-                if (idle && q_next < q_n) {
-                    const int idx = q_next + __popcll(idle & below);
-                    if (!have && idx < q_n) {
-                        const unsigned e = q_start[idx];
-                        const int slot = q_slot[idx];
-                        c.roi = g_roi[slot];
-                        c.pos = (int)(e & 0x3fffffffu);
-                        c.is_hole = (int)(e >> 31);
-                        img = arena + g_img[slot];
-                        rs = (unsigned)g_rs[slot];
-                        const int ns = g_ns[slot];
-                        // lean_begin on the bit image
-                        const int i0 = c.pos - c.is_hole;
-                        const int x = i0 % ns, y = i0 / ns;
-                        w.xy = w.xy0 = (unsigned)x | ((unsigned)y << 16);
-                        w.cxy = w.xy0 + (unsigned)c.is_hole;
-                        w.npts = 0;
-                        w.step = 0;
-                        w.status = -1;
-                        w.xy1 = 0; w.pe = 0; w.from = 0;
-                        w.m = (y >= 1) ? lds_mask(img, rs, (unsigned)x, (unsigned)y, nb_lut) : 0u;
-                        if (w.m == 0) {
-                            w.status = TRACE_SINGLE;
-                            w.npts = 1;
-                        } else {
-                            const int s0 = first_cw(w.m, (c.is_hole ? 0 : 4) - 1);
-                            w.xy1 = w.xy0 + (unsigned)(step_dx(s0) + 65536 * step_dy(s0));
-                            w.pe = (unsigned)(s0 ^ 4) << 10;
-                            w.from = (unsigned)(s0 + 1) & 7u;
-                        }
-                        have = true;
-                        flushed = 0;
-                    }
-                    q_next += __popcll(idle);
-                }
-            }
-            if (__ballot(have) == 0) break;
-            for (int k = 0; k < MID_BLOCK; k++) {
-                const bool running = have && w.status < 0;
-                if (__ballot(running) == 0) break;
-                if (running) {
-                    // lean_step with the next pixel's mask from the bit image
-                    const unsigned mm = __builtin_amdgcn_perm(w.m, w.m, 0u);
-                    const unsigned t = (unsigned)__builtin_ctz(__builtin_amdgcn_alignbit(mm, mm, w.from));
-                    const unsigned ent = step_tab[(t << 3) + w.from];
-                    const int d = (int)(w.xy - w.cxy);
-                    const unsigned nf = ((ent << 1) & (unsigned)(d + 1)) | (ent & (unsigned)d);
-                    const unsigned nxy = w.xy + (ent & LW_DELTA) - 0x10001u;
-                    const bool closes = (nxy == w.xy0) & (w.xy == w.xy1);
-                    const unsigned e = ent & LW_EXIT;
-                    const bool emit = e != w.pe;
-                    const unsigned m4 = lds_mask(img, rs, nxy & 0xffffu, nxy >> 16, nb_lut);
-                    const int slot = w.npts - flushed;
-                    my_row[slot < MID_BLOCK ? slot : MID_BLOCK] = w.xy;
-                    w.npts += emit ? 1 : 0;
-                    w.status = (int)nf < 0 ? (int)TRACE_NOT_FIRST : closes ? (int)TRACE_OK : m4 == 0u ? (int)TRACE_OVERRUN : -1;
-                    w.step += 1;
-                    w.xy = nxy;
-                    w.pe = e;
-                    w.from = (ent >> 5) & 7u;
-                    w.m = m4;
-                }
-            }
-            if (have && w.status < 0 && w.step >= budget) w.status = TRACE_OVERRUN;
-            {   // append the parked points to the slabs (as in follow_mid_kernel)
-                const int stored = w.npts < SLAB_PTS ? w.npts : SLAB_PTS;
-                const int pend = have ? stored - flushed : 0;
-                unsigned long long fm = __ballot(pend > 0);
-                if (fm) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                const int grp = lane / FLUSH_W, k = lane % FLUSH_W;
-                while (fm) {
-                    int L = 0, cnt = 0, off = 0;
-#pragma unroll
-                    for (int g = 0; g < 64 / FLUSH_W; g++) {
-                        const int Lg = fm ? __ffsll((long long)fm) - 1 : 0;
-                        const int cg = fm ? __builtin_amdgcn_readlane(pend, Lg) : 0;
-                        const int og = __builtin_amdgcn_readlane(flushed, Lg);
-                        fm &= fm - 1;
-                        L = grp == g ? Lg : L;
-                        cnt = grp == g ? cg : cnt;
-                        off = grp == g ? og : off;
-                    }
-                    if (k < cnt) wave_slabs[(size_t)L * SLAB_STRIDE + off + k] = parked[L * POINT_ROW + k];
-                }
-                flushed += pend;
-            }
-            // retire: 1 = to the wave tier (budget or slab exhausted: it follows the border again from its start on the byte plane),
-            // 3 = closed border, published for follow_finish_kernel
-            int route = 0;
-            if (have && w.status >= 0) {
-                if (w.status == TRACE_OVERRUN) route = 1;
-                else if (w.status == TRACE_OK && w.npts >= 4) route = w.npts <= SLAB_PTS ? 3 : 1;
-                have = false;
-            }
-            const unsigned long long todo = __ballot(route == 3);
-            if (todo) {
-                int my_off = 0, total = 0;
-                for (unsigned long long t = todo; t; t &= t - 1) {
-                    const int L = __ffsll((long long)t) - 1;
-                    const int nl = __builtin_amdgcn_readlane(w.npts, L);
-                    my_off = lane == L ? total : my_off;
-                    total += nl;
-                }
-                const int cnt = __popcll(todo);
-                unsigned long long pbase = 0;
-                int fbase = 0;
-                if (ticket_lane() == 0) {
-                    pbase = atomicAdd(reinterpret_cast<unsigned long long*>(ws.counters + CNT_POOL_INTS), (unsigned long long)total);
-                    fbase = atomicAdd(ws.counters + CNT_FIN_C, cnt);
-                }
-                pbase = uni(pbase);
-                fbase = uni(fbase);
-                if ((long long)pbase + total > ws.cap_pool_ints || fbase + cnt > ws.cap_fin) {
-                    if (lane == 0) atomicOr(ws.counters + CNT_ERR, (long long)pbase + total > ws.cap_pool_ints ? ERR_POOL_OVERFLOW : ERR_CAND_OVERFLOW);
-                } else {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    for (unsigned long long t = todo; t; t &= t - 1) {
-                        const int L = __ffsll((long long)t) - 1;
-                        const int nl = __builtin_amdgcn_readlane(w.npts, L);
-                        const int ol = __builtin_amdgcn_readlane(my_off, L);
-                        const unsigned* src = wave_slabs + (size_t)L * SLAB_STRIDE;
-                        unsigned* dst = reinterpret_cast<unsigned*>(ws.pool) + pbase + ol;
-                        for (int i0 = 0; i0 < nl; i0 += 64 * 8) {
-                            unsigned v[8];
-#pragma unroll
-                            for (int u = 0; u < 8; u++) {
-                                const int i = i0 + lane + 64 * u;
-                                v[u] = i < nl ? src[i] : 0u;
-                            }
-#pragma unroll
-                            for (int u = 0; u < 8; u++) {
-                                const int i = i0 + lane + 64 * u;
-                                if (i < nl) dst[i] = v[u];
-                            }
-                        }
-                    }
-                    if (route == 3) {
-                        FinishRec r;
-                        r.roi = c.roi; r.pos = c.pos; r.is_hole = c.is_hole; r.npts = w.npts;
-                        r.off = (long long)pbase + my_off;
-                        ws.fin_crop[fbase + __popcll(todo & below)] = r;
-                    }
-                }
-            }
-            const unsigned long long mask = __ballot(route == 1);
-            if (mask) {
-                int qbase = 0;
-                const int leader = __ffsll((long long)mask) - 1;
-                if (lane == leader) qbase = atomicAdd(ws.counters + CNT_LONG_C, __popcll(mask));
-                qbase = __builtin_amdgcn_readlane(qbase, leader);
-                if (route == 1) {
-                    const int slot = qbase + __popcll(mask & below);
-                    if (slot < ws.cap_long) ws.long_crop[slot] = c;
-                    else atomicOr(ws.counters + CNT_ERR, ERR_CAND_OVERFLOW);
-                }
-            }
-        }
-    }
-}
-
-// Finishing: one wave per published border -- its points from the pool into LDS, statistics, cvApproxPoly, the quad filter,
-// publication of the quad (wave_finish_packed).  Records are dealt out round-robin, wave w of the grid taking w, w + waves, ...:
-// one ticket per border through a single counter (~90 atomics per microsecond chip-wide) would be this kernel's whole duration.
-__global__ __launch_bounds__(64) void follow_finish_kernel(Workspace ws) {
-    __shared__ WaveScratch scratch;
-    __shared__ unsigned staged[LDS_PTS];
-    int n = ws.counters[CNT_FIN_C];
-    if (n > ws.cap_fin) n = ws.cap_fin;
-    for (int idx = (int)blockIdx.x; idx < n; idx += (int)gridDim.x) {
-        const FinishRec r = ws.fin_crop[idx];
-        StartCand c;
-        c.roi = uni(r.roi);
-        c.pos = uni(r.pos);
-        c.is_hole = uni(r.is_hole);
-        const int npts = uni(r.npts);
-        const unsigned* pts = reinterpret_cast<const unsigned*>(ws.pool) + uni((unsigned long long)r.off);
-        const PlaneRef pl = plane_of<true>(ws, c.roi);
-        // a border that starts behind the crop's best quad so far cannot replace it
-        const bool beaten = uni((unsigned)(ws.best_crop[c.roi] >> 32)) < (unsigned)c.pos;
-        if (!beaten) wave_finish_packed<true, true>(ws, c, pl, pts, npts, staged, &scratch);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the staging area is reused by the next border
-    }
-}
-
 // ---- Phase B: one wave per long border, walking inside an LDS tile cache -------------------------------------
 // The follower's step needs the neighbour mask of the pixel it just moved to: a dependent byte load, i.e. one
 // HBM/L2 latency per step when done from global memory.  Here the wave cooperatively copies a TILE x TILE window
@@ -1604,7 +1247,6 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
                     ws.rois_crop[r] = roi;
                     ws.best_crop[r] = ~0ull;
                     ws.crop_min_rest[r] = 0x7fffffff;
-                    ws.crop_nstarts[r] = 0;
                     for (int t = 0; t < ntx * nty; t++) {
                         TileDesc td;
                         td.roi = r; td.x0 = t % ntx; td.y0 = (t / ntx) * MARCH_CROP_ROWS;
@@ -1628,17 +1270,6 @@ void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_mid_kernel<false>, dim3(ws.mid_blocks * (4 / FW)), dim3(FOLLOW_THREADS), 0, stream, ws, 0);
 }
 void launch_follow_mid_crops(const Workspace& ws, hipStream_t stream) {
-    if (ws.crop_lds) {
-        // crop walker (one slab per lane: the grid is bounded by the slabs), the finishing kernel, then the byte-plane kernel for
-        // what the walker handed back (crops with more than CS_CAP starts, crops larger than a wave's arena): usually nothing
-        int blocks = ws.walk_blocks;
-        const int max_blocks = ws.max_mid_blocks * 4;
-        if (blocks > max_blocks) blocks = max_blocks;
-        hipLaunchKernelGGL(crop_walk_kernel, dim3(blocks), dim3(64), 0, stream, ws);
-        hipLaunchKernelGGL(follow_finish_kernel, dim3(ws.fin_blocks), dim3(64), 0, stream, ws);
-        hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(64), dim3(FOLLOW_THREADS), 0, stream, ws, 0);
-        return;
-    }
     if (ws.crop_phases == 1) {
         hipLaunchKernelGGL(follow_mid_kernel<true>, dim3(ws.mid_blocks * (4 / FW)), dim3(FOLLOW_THREADS), 0, stream, ws, 0);
         return;

@@ -35,13 +35,6 @@ enum { ERR_CAND_OVERFLOW = 1, ERR_POOL_OVERFLOW = 2, ERR_QUAD_OVERFLOW = 4, ERR_
 
 struct TileDesc { int roi, x0, y0; };   // binarise work unit of the crop pass: x0 = strip index, y0 = first row
 
-struct FinishRec {   // a closed border published by the crop walker for follow_finish_kernel
-    int roi, pos, is_hole, npts;
-    long long off;       // its npts packed points (x | y << 16) in the point pool, in ints from the pool's start
-};
-
-constexpr int CS_CAP = 32;   // starts of one crop kept in the crop's own array (crop walker); more go to the tier-2 lists
-
 struct CandRec {   // pre-dedupe candidate, slot [frame][quad][template]
     int valid, orient;
     long long bit;
@@ -55,8 +48,7 @@ enum { CNT_FRAME_CANDS = 0, CNT_CROP_ROIS = 1, CNT_CROP_TILES = 2, CNT_CROP_CAND
        CNT_CROP_PIXELS = 10 /* 64-bit, uses 10..11 */, CNT_LONG_F = 12, CNT_LONG_C = 13, CNT_TICKET_LF = 14, CNT_TICKET_LC = 15,
        CNT_MID_F = 16, CNT_MID_C = 17, CNT_TICKET_MF = 18, CNT_TICKET_MC = 19, CNT_TICKET_BC = 20, CNT_MID_C_FIRST = 21, CNT_TICKET_MC2 = 22,
        CNT_POSE_JOBS = 23,
-       CNT_PROF = 24 /* 32 64-bit profiling slots, written only by builds with -DOCVAR_PROF (tools/prof_tier2.py) */,
-       CNT_FIN_C = 88, CNT_COUNT = 96 };
+       CNT_PROF = 24 /* 32 64-bit profiling slots, written only by builds with -DOCVAR_PROF (tools/prof_tier2.py) */, CNT_COUNT = 88 };
 
 struct Workspace {
     // limits
@@ -84,13 +76,7 @@ struct Workspace {
     StartCand* long_frame;  // starts whose border exceeded tier 2's step budget
     StartCand* long_crop;
     int cap_long;
-    // crop walker (follow.hip::crop_walk_kernel): the crop pass's tier 2 from bit images in LDS
-    int crop_lds;           // 1: tier 1 files a crop's surviving starts in the crop's own array and the crop walker takes them
-    unsigned* crop_starts;  // [cap_crop_rois][CS_CAP]: pos | frame-border flag << 30 | is_hole << 31
-    int* crop_nstarts;      // [cap_crop_rois]
-    FinishRec* fin_crop;    // closed borders waiting for follow_finish_kernel (counter CNT_FIN_C)
-    int cap_fin, fin_blocks, walk_blocks;
-    int* pool;              // published borders' points; tier 3's borders with more points than a wave slab holds
+    int* pool;              // points + DP stacks
     int* slab;              // [max_mid_blocks*256][SLAB_STRIDE] private point space of the tier-2 lanes
     int* slab3;             // [max_long_blocks*4][SLAB3_STRIDE] point space of the tier-3 waves
     QuadRec* quads_frame;   // [B][maxq] unordered
