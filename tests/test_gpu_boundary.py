@@ -428,6 +428,40 @@ def test_host_entry_uses_a_buffer_the_caller_page_locked_in_place():
     assert np.array_equal(plain, pinned) and not np.array_equal(plain, frames)   # both greyed in place
 
 
+def test_stage_stamps_put_two_contexts_on_one_clock():
+    """ocvar_hip_stage_stamps: the 13 stage boundaries of a batch in ms after a reference event of the caller's -- increasing
+    within a batch, consistent with ocvar_hip_stage_ms, and comparable between contexts (bench.py derives from them how long a
+    kernel was on the GPU while several contexts ran)."""
+    import torch
+    import opencv_ar_amd as oa
+    cfg = H.synth_config(2)
+    names = ["2x2-01"]
+    n = 8
+    tpls = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, x + ".png") for x in names])
+    cam = oa.default_camera(cfg.width, cfg.height)
+    frames = np.stack([H.synth_frame(cfg, f, names)[0] for f in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    dets = []
+    for _ in range(2):
+        det = oa.Detector(cfg.width, cfg.height, max_batch=n)
+        det.set_templates(tpls)
+        det.set_camera(cam)
+        dets.append(det)
+    ref = torch.cuda.Event(enable_timing=True)
+    ref.record()
+    ref.synchronize()
+    for det in dets:
+        det.enqueue_device(d.data_ptr(), cfg.width, cfg.height, n)
+    for det in dets:
+        det.collect(8)
+    stamps = [det.stage_stamps(ref.cuda_event) for det in dets]
+    for det, st in zip(dets, stamps):
+        assert len(st) == 13 and st[0] > 0 and (np.diff(st) >= 0).all()
+        ms = det.stage_ms()
+        assert np.allclose(np.diff(st)[:11], ms[:11], atol=0.02) and abs((st[12] - st[0]) - ms[11]) < 0.02
+    assert abs(stamps[0][0] - stamps[1][0]) < 1000.0   # the same clock: both batches started within a second of the reference
+
+
 def test_ready_and_result_limit():
     """ocvar_hip_ready turns 1 once the batch is done (collect then returns at once); a result limit of 2 records per frame
     brings the first two markers of every frame to the host and leaves the counts alone."""

@@ -145,6 +145,22 @@ def test_png_reader_colour_types_and_filters(host):
         if m:
             seen.add((int(m.group(1)), int(m.group(2))))
     assert seen == {(c, f) for c in (0, 2, 3, 4, 6) for f in range(5)}
+    # what the reader does not decode is refused as a whole (return 0), never mis-read: 16-bit samples, Adam7 interlacing
+    import struct
+    import zlib
+
+    def png(depth, ctype, interlace, raw):
+        def chunk(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, depth, ctype, 0, 0, interlace)) +
+                chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    import tempfile as _tf
+    with _tf.TemporaryDirectory() as d:
+        for label, data in (("16bit", png(16, 0, 0, b"".join(b"\0" + bytes(8) for _ in range(4)))),
+                            ("interlaced", png(8, 0, 1, bytes(40)))):
+            p = os.path.join(d, label + ".png")
+            open(p, "wb").write(data)
+            assert host.cvarLoadTemplateTag(C.byref(H.Template()), p.encode(), 0.01) == 0, label
     # damaged files are refused (return 0, opencvar.cpp:286-288), never half-read
     good = open(os.path.join(png_dir, "4x4-01-c6-f4.png"), "rb").read()
     import tempfile
