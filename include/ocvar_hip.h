@@ -166,6 +166,20 @@ int ocvar_hip_pipe_detect_device(OcvarPipe* pipe, uint8_t* d_bgr, int width, int
 int ocvar_hip_pipe_track_device(OcvarPipe* pipe, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride,
                                 long long n_streams, int grey_in_place, int reset, OcvarMarker* markers, int* counts, int max_per_frame);
 
+/* Streaming form for a caller with an endless supply of frames (the many-cameras form of the reference's per-frame loop,
+ * samples/ARTest.cpp:43-82): the pipeline of contexts is kept full instead of being filled and drained per call.  submit hands
+ * a chunk of n_frames <= chunk_frames device-resident frames to the next context and returns at once (OCVAR_E_BUSY when every
+ * context already has a chunk in flight); collect waits for the OLDEST chunk in flight, writes its markers [n][max_per_frame]
+ * and counts [n], stores the tag it was submitted under and returns its frame count n (0: nothing in flight, < 0: error).
+ * Stateless.  set_result_limit (only while nothing is in flight): how many marker records per frame the chunks bring to the
+ * host, as ocvar_hip_set_result_limit. */
+enum { OCVAR_E_BUSY = -6 };
+int ocvar_hip_pipe_submit(OcvarPipe* pipe, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride, int n_frames,
+                          int grey_in_place, long long tag);
+int ocvar_hip_pipe_collect(OcvarPipe* pipe, long long* tag, OcvarMarker* markers, int* counts, int max_per_frame);
+int ocvar_hip_pipe_in_flight(const OcvarPipe* pipe);
+int ocvar_hip_pipe_set_result_limit(OcvarPipe* pipe, int max_per_frame);
+
 /* Same, frames in host memory (copied over PCIe first; greyed frames are copied back when requested). */
 int ocvar_hip_detect_host(OcvarHip* ctx, uint8_t* h_bgr, int width, int height, int row_stride, size_t frame_stride,
                           int n_frames, int grey_in_place, const OcvarMarker* prev, const int* prev_counts,

@@ -23,7 +23,7 @@ MAX_TEMPLATES, MAX_QUADS, MAX_MARKERS = 16, 256, 64
 HIP_SYMBOLS = [
     "ocvar_hip_create", "ocvar_hip_create_ex", "ocvar_hip_capacity_flags", "ocvar_hip_gate_create", "ocvar_hip_gate_destroy", "ocvar_hip_set_gate", "ocvar_hip_ready", "ocvar_hip_set_result_limit",
     "ocvar_hip_pipe_create", "ocvar_hip_pipe_destroy", "ocvar_hip_pipe_last_error", "ocvar_hip_pipe_set_templates", "ocvar_hip_pipe_set_camera",
-    "ocvar_hip_pipe_detect_device", "ocvar_hip_pipe_track_device", "ocvar_hip_enqueue_tracked", "ocvar_hip_build_info", "ocvar_hip_set_tuning", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
+    "ocvar_hip_pipe_detect_device", "ocvar_hip_pipe_track_device", "ocvar_hip_pipe_submit", "ocvar_hip_pipe_collect", "ocvar_hip_pipe_in_flight", "ocvar_hip_pipe_set_result_limit", "ocvar_hip_enqueue_tracked", "ocvar_hip_build_info", "ocvar_hip_set_tuning", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
     "ocvar_hip_detect_device", "ocvar_hip_enqueue", "ocvar_hip_collect", "ocvar_hip_detect_host", "ocvar_hip_find_squares",
     "ocvar_hip_debug_gray", "ocvar_hip_debug_binary", "ocvar_hip_debug_frame_quads", "ocvar_hip_debug_candidates",
     "ocvar_hip_stage_ms", "ocvar_hip_stage_stamps", "ocvar_hip_counters", "ocvar_hip_results_to_device", "ocvar_hip_results_to_device_ex", "ocvar_hip_debug_calibrate",
@@ -95,6 +95,10 @@ def hip_lib():
         lib.ocvar_hip_pipe_set_camera.argtypes = [vp, vp]
         lib.ocvar_hip_pipe_detect_device.argtypes = [vp, vp, i, i, i, sz, C.c_longlong, i, vp, vp, i]
         lib.ocvar_hip_pipe_track_device.argtypes = [vp, vp, i, i, i, sz, C.c_longlong, i, i, vp, vp, i]
+        lib.ocvar_hip_pipe_submit.argtypes = [vp, vp, i, i, i, sz, i, i, C.c_longlong]
+        lib.ocvar_hip_pipe_collect.argtypes = [vp, C.POINTER(C.c_longlong), vp, vp, i]
+        lib.ocvar_hip_pipe_in_flight.argtypes = [vp]
+        lib.ocvar_hip_pipe_set_result_limit.argtypes = [vp, i]
         lib.ocvar_hip_enqueue_tracked.argtypes = [vp, vp, i, i, i, sz, i, i, vp, vp, vp]
         lib.ocvar_hip_set_tuning.argtypes = [vp, i, i]
         lib.ocvar_hip_build_info.argtypes = []
@@ -227,6 +231,34 @@ class Pipe:
         self._check(self._lib.ocvar_hip_pipe_detect_device(self._p, d_ptr, width, height, row_stride, frame_stride, n_frames,
                                                            int(grey_in_place), _ptr(markers), _ptr(counts), max_per_frame), "pipe_detect_device")
         return markers, counts
+
+    def submit(self, d_ptr, width, height, n_frames, tag=0, row_stride=None, frame_stride=None, grey_in_place=False):
+        """streaming form: hand the next chunk to the next context; False when every context already has one in flight"""
+        row_stride = row_stride or 3 * width
+        frame_stride = frame_stride or row_stride * height
+        rc = self._lib.ocvar_hip_pipe_submit(self._p, d_ptr, width, height, row_stride, frame_stride, n_frames, int(grey_in_place), tag)
+        if rc == -6:
+            return False
+        self._check(rc, "pipe_submit")
+        return True
+
+    def collect(self, max_frames, max_per_frame=MAX_MARKERS):
+        """the oldest chunk in flight: (tag, markers [n][max_per_frame], counts [n]) or None when nothing is in flight"""
+        markers = np.zeros((max_frames, max_per_frame), MARKER_DTYPE)
+        counts = np.zeros(max_frames, np.int32)
+        tag = C.c_longlong(0)
+        n = self._lib.ocvar_hip_pipe_collect(self._p, C.byref(tag), _ptr(markers), _ptr(counts), max_per_frame)
+        if n < 0:
+            self._check(n, "pipe_collect")
+        if n == 0:
+            return None
+        return tag.value, markers[:n], counts[:n]
+
+    def in_flight(self):
+        return self._lib.ocvar_hip_pipe_in_flight(self._p)
+
+    def set_result_limit(self, max_per_frame):
+        self._check(self._lib.ocvar_hip_pipe_set_result_limit(self._p, max_per_frame), "pipe_set_result_limit")
 
     def track_device(self, d_ptr, width, height, n_streams, reset=False, row_stride=None, frame_stride=None, grey_in_place=False,
                      max_per_frame=MAX_MARKERS):

@@ -149,6 +149,8 @@ extern "C" int ocvar_hip_create_ex(OcvarHip** out, int device, int max_width, in
     if ((rc = dev_alloc(c, &w.quads_crop, (size_t)w.cap_crop_quads))) return rc;
     if ((rc = dev_alloc(c, &w.best_crop, (size_t)w.cap_crop_rois))) return rc;
     if ((rc = dev_alloc(c, &w.crop_min_rest, (size_t)w.cap_crop_rois))) return rc;
+    if ((rc = dev_alloc(c, &w.ring_frame, B))) return rc;
+    if ((rc = dev_alloc(c, &w.ring_crop, (size_t)w.cap_crop_rois))) return rc;
     if ((rc = dev_alloc(c, &w.cand_recs, B * max_quads * MAXT))) return rc;
     if ((rc = dev_alloc(c, &w.prev, B * MAXM))) return rc;
     if ((rc = dev_alloc(c, &w.n_prev, B))) return rc;
@@ -441,6 +443,7 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
     if (only_binarise) stages = 0;
     if (stages > 0) {
         HIP_TRY(c, stage(1, 0));
+        launch_ring_quads_frames(w, cur);
         launch_follow_frames(w, cur);
         TRACE_LAUNCH("follow tier 1 (frames)", cur);
         HIP_TRY(c, stage(2, 1));
@@ -464,6 +467,7 @@ static int enqueue_impl(OcvarHip* c, uint8_t* d_bgr, int width, int height, int 
         if (gate_mode != 1) HIP_TRY(c, gate_leave(c->gate, s));
         TRACE_LAUNCH("binarise_crops", s);
         HIP_TRY(c, stage(6, 4));
+        if (!(skip_crop & 2)) launch_ring_quads_crops(w, cur);
         if (!(skip_crop & 2)) launch_follow_crops(w, cur);
         TRACE_LAUNCH("follow tier 1 (crops)", cur);
         HIP_TRY(c, stage(7, 5));

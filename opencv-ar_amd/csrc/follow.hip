@@ -600,7 +600,10 @@ __global__ __launch_bounds__(FOLLOW_THREADS) void follow_kernel(Workspace ws) {
             if (idx < tk_end) {
                 cc = cands[idx];
                 const PlaneRef pl = plane_of<CROP>(ws, cc.roi);
-                if (cc.pos > 0 && cc.pos < pl.plane && !run_has_earlier_pixel_rows(pl.nbr, pl.ns, cc.pos, cc.is_hole))
+                // (the ROI's own frame border -- the outer start at pixel (1, 1) -- is a rectangle when the ROI's ring of pixels next to
+                // its zeroed frame is all set; ring_quads_kernel has then published what the walk would find: nothing to follow)
+                const bool ring_done = !cc.is_hole && cc.pos == pl.ns + 1 && (CROP ? ws.ring_crop : ws.ring_frame)[cc.roi] != 0;
+                if (!ring_done && cc.pos > 0 && cc.pos < pl.plane && !run_has_earlier_pixel_rows(pl.nbr, pl.ns, cc.pos, cc.is_hole))
                     alive = trace_flat(pl.nbr, pl.ns, pl.plane, cc.pos, cc.is_hole, nullptr, 0, PRE_STEPS).status == TRACE_OVERRUN;
             }
             const unsigned long long mask = __ballot(alive);
@@ -626,6 +629,63 @@ __global__ __launch_bounds__(FOLLOW_THREADS) void follow_kernel(Workspace ws) {
     append(0, o_n0);
     append(1, o_n1);
     if (CROP) append(2, o_n2);
+}
+
+// ---- the ROI's own frame border without a walk --------------------------------------------------------------------------------
+// cvFindContours zeroes the 1-pixel frame of the image it is given (a whole frame, or a crop), so the first border of almost every
+// ROI is the outer border of the background region that touches that frame: found at pixel (1, 1), it runs once round the ROI -- 6000
+// steps for a 1080p frame, ~700 for a crop: the longest walk of its ROI, a third of the crop pass's steps and, for one frame per call,
+// the longest dependent chain of the whole call.  If the ring of pixels next to the zeroed frame (rows 1 and sh-2, columns 1 and sw-2)
+// is all set, that border is exactly the rectangle (1,1) (1,sh-2) (sw-2,sh-2) (sw-2,1) -- the follower keeps the zeroed frame on one
+// side and the next ring pixel is always there, whatever lies inside -- with these four corner points in this order (the walk runs
+// down the left side first).  One wave per ROI checks the ring on the mask plane (bit 4 of a mask byte = the pixel to the west is set,
+// bit 0 = the pixel to the east): a handful of independent loads instead of a dependent chain; lane 0 then runs the same
+// approximation and filter on the four points as on any stored border and publishes the quad if it is one.  ring[roi] tells tier 1
+// to drop the start.  A ring with a hole in it: ring[roi] = 0, the border is walked as before.
+template <bool CROP>
+__global__ __launch_bounds__(64) void ring_quads_kernel(Workspace ws) {
+    int n = CROP ? ws.counters[CNT_CROP_ROIS] : ws.n_frames;
+    if (CROP && n > ws.cap_crop_rois) n = ws.cap_crop_rois;
+    int* ring = CROP ? ws.ring_crop : ws.ring_frame;
+    const int lane = threadIdx.x;
+    for (int roi = blockIdx.x; roi < n; roi += gridDim.x) {
+        const PlaneRef pl = plane_of<CROP>(ws, roi);
+        const int ns = uni(pl.ns), sh = uni(pl.sh), sw = uni(pl.img_w) & ~1;
+        bool bad = sw < 8 || sh < 8;
+        if (!bad) {
+            // rows 1 and sh-2: pixel x in [1, sw-2] is bit 4 of mask byte x+1
+            const int tiles = ns >> 4;
+            for (int i = lane; i < 2 * tiles; i += 64) {
+                const int y = i < tiles ? 1 : sh - 2, xt = i < tiles ? i : i - tiles;
+                const uint4 v = *reinterpret_cast<const uint4*>(pl.nbr + nbr_addr(xt << 4, y, ns));
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int xb = (xt << 4) + k;   // mask byte of pixel xb: its west neighbour is pixel xb-1
+                    if (xb >= 2 && xb <= sw - 1 && !((w[k >> 2] >> (8 * (k & 3) + 4)) & 1u)) bad = true;
+                }
+            }
+            // columns 1 and sw-2, rows 1 .. sh-2: bit 4 of mask(2, y), bit 0 of mask(sw-3, y)
+            for (int y = 1 + lane; y <= sh - 2; y += 64) {
+                const unsigned a = pl.nbr[nbr_addr(2, y, ns)], b = pl.nbr[nbr_addr(sw - 3, y, ns)];
+                if (!((a >> 4) & 1u) || !(b & 1u)) bad = true;
+            }
+        }
+        const bool clean = __ballot(bad) == 0;
+        if (lane == 0) {
+            ring[roi] = clean ? 1 : 0;
+            if (clean && (long long)(sw - 3) * (sh - 3) > 500) {   // (worth_approximating: the quad filter needs |area| > 500)
+                const int pts[8] = {1, 1, 1, sh - 2, sw - 2, sh - 2, sw - 2, 1};
+                const TraceStats st = stats_of_points(pts, 4);
+                StartCand c;
+                c.roi = roi;
+                c.pos = ns + 1;
+                c.is_hole = 0;
+                DpSlice stack[DP_STACK];
+                approximate_and_emit<CROP>(ws, c, pl, pts, 4, st.perimeter, stack);
+            }
+        }
+    }
 }
 
 // ---- the follower's step from a table (tier 2) ------------------------------------------------------------------------------
@@ -1260,6 +1320,12 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
     }
 }
 
+void launch_ring_quads_frames(const Workspace& ws, hipStream_t stream) {
+    hipLaunchKernelGGL(ring_quads_kernel<false>, dim3(ws.n_frames < 4096 ? ws.n_frames : 4096), dim3(64), 0, stream, ws);
+}
+void launch_ring_quads_crops(const Workspace& ws, hipStream_t stream) {
+    hipLaunchKernelGGL(ring_quads_kernel<true>, dim3(ws.n_frames >= 128 ? 4096 : ws.n_frames * 32), dim3(64), 0, stream, ws);
+}
 void launch_follow_frames(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_kernel<false>, dim3(ws.short_blocks * (4 / FW)), dim3(FOLLOW_THREADS), 0, stream, ws);
 }

@@ -89,6 +89,8 @@ struct Workspace {
     unsigned long long* crop_pixels;   // = counters + CNT_CROP_PIXELS: running sum of crop plane sizes (pool cursor)
     QuadRec* quads_crop;    // pool
     unsigned long long* best_crop;     // [cap_crop_rois] (start<<32 | quad slot), ~0 = none
+    int* ring_frame;        // [B] 1: the frame's own frame border is the rectangle ring_quads_kernel has published (tier 1 drops its start)
+    int* ring_crop;         // [cap_crop_rois] the same for a crop
     int* crop_min_rest;     // [cap_crop_rois] smallest start position among a crop's tier-2 starts off the crop's frame (tier 2 walks these first)
     CandRec* cand_recs;     // [B][maxq][MAXT]
     MarkerRec* prev;        // [B][MAXM]
@@ -107,6 +109,8 @@ struct Workspace {
 void launch_binarise_frames(const Workspace& ws, const uint8_t* d_bgr, int row_stride, size_t frame_stride, int grey_in_place,
                             hipStream_t stream);
 void launch_binarise_crops(const Workspace& ws, hipStream_t stream);
+void launch_ring_quads_frames(const Workspace& ws, hipStream_t stream);   // the ROIs' own frame borders without a walk (before tier 1)
+void launch_ring_quads_crops(const Workspace& ws, hipStream_t stream);
 void launch_follow_frames(const Workspace& ws, hipStream_t stream);
 void launch_follow_crops(const Workspace& ws, hipStream_t stream);
 void launch_follow_mid_frames(const Workspace& ws, hipStream_t stream);

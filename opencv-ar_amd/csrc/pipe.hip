@@ -18,6 +18,10 @@ struct OcvarPipe {
     std::vector<OcvarHip*> ctx;
     OcvarGate* gate = nullptr;
     // tracking state of ocvar_hip_pipe_track_device: every stream's markers of the last step, on the device
+    // streaming form (ocvar_hip_pipe_submit / _collect): chunk k runs on context k % n_ctx; chunks [tail, head) are in flight
+    long long head = 0, tail = 0;
+    std::vector<long long> tags;
+    std::vector<int> counts_in_flight;
     OcvarMarker* d_state = nullptr;
     int* d_state_counts = nullptr;
     long long state_streams = 0;
@@ -48,6 +52,8 @@ extern "C" int ocvar_hip_pipe_create(OcvarPipe** out, int device, int max_width,
         const int rc = ocvar_hip_gate_create(&p->gate, device, gate_width);
         if (rc) { p->err = "ocvar_hip_gate_create failed"; return rc; }
     }
+    p->tags.assign((size_t)n_contexts, 0);
+    p->counts_in_flight.assign((size_t)n_contexts, 0);
     for (int i = 0; i < n_contexts; i++) {
         OcvarHip* c = nullptr;
         const int rc = ocvar_hip_create(&c, device, max_width, max_height, chunk_frames);
@@ -178,4 +184,49 @@ extern "C" int ocvar_hip_pipe_track_device(OcvarPipe* p, uint8_t* d_bgr, int wid
         (void)hipDeviceSynchronize();
     }
     return rc;
+}
+
+// ---- streaming form --------------------------------------------------------------------------------------------------------
+// ocvar_hip_pipe_detect_device fills and drains the pipeline once per call (159 k frames/s per 16 384-frame call against the 197 k
+// of a pipeline that never drains).  A caller with an endless supply of frames -- video servers: the reference's per-frame loop,
+// samples/ARTest.cpp:43-82, for many cameras -- keeps it full instead: submit hands the next chunk to the next context (stream
+// order per context, the shared gate between them) and returns at once; collect waits for the OLDEST chunk in flight and returns
+// its results with the tag it was submitted under.  At most n_contexts chunks are in flight.
+
+extern "C" int ocvar_hip_pipe_in_flight(const OcvarPipe* p) { return p ? (int)(p->head - p->tail) : 0; }
+
+extern "C" int ocvar_hip_pipe_submit(OcvarPipe* p, uint8_t* d_bgr, int width, int height, int row_stride, size_t frame_stride, int n_frames,
+                                     int grey_in_place, long long tag) {
+    if (!p || !d_bgr || n_frames < 1 || n_frames > p->chunk) return OCVAR_E_ARG;
+    if (p->head - p->tail >= p->n_ctx) {
+        p->err = "every context has a chunk in flight: collect one first";
+        return OCVAR_E_BUSY;
+    }
+    const int i = (int)(p->head % p->n_ctx);
+    const int rc = ocvar_hip_enqueue(p->ctx[i], d_bgr, width, height, row_stride, frame_stride, n_frames, grey_in_place, nullptr, nullptr, nullptr);
+    if (rc) { p->err = ocvar_hip_last_error(p->ctx[i]); return rc; }
+    p->tags[i] = tag;
+    p->counts_in_flight[i] = n_frames;
+    p->head++;
+    return OCVAR_OK;
+}
+
+extern "C" int ocvar_hip_pipe_collect(OcvarPipe* p, long long* tag, OcvarMarker* markers, int* counts, int max_per_frame) {
+    if (!p || !counts || max_per_frame < 0 || (max_per_frame > 0 && !markers)) return OCVAR_E_ARG;
+    if (p->head == p->tail) return 0;   // nothing in flight
+    const int i = (int)(p->tail % p->n_ctx);
+    const int rc = ocvar_hip_collect(p->ctx[i], markers, counts, max_per_frame);
+    p->tail++;   // (the chunk is gone either way: a failed batch is not collected twice)
+    if (rc) { p->err = ocvar_hip_last_error(p->ctx[i]); return rc; }
+    if (tag) *tag = p->tags[i];
+    return p->counts_in_flight[i];
+}
+
+extern "C" int ocvar_hip_pipe_set_result_limit(OcvarPipe* p, int max_per_frame) {
+    if (!p || p->head != p->tail) return OCVAR_E_ARG;
+    for (OcvarHip* c : p->ctx) {
+        const int rc = ocvar_hip_set_result_limit(c, max_per_frame);
+        if (rc) return rc;
+    }
+    return OCVAR_OK;
 }

@@ -355,6 +355,48 @@ def test_pipe_of_contexts_equals_one_context():
         assert m1.tobytes() == m2.tobytes()
 
 
+def test_pipe_streaming_submit_collect():
+    """ocvar_hip_pipe_submit / _collect: chunks handed to the contexts as the caller produces them, collected oldest first with
+    their tags; OCVAR_E_BUSY when every context has one in flight; results equal one context's on the same frames."""
+    import torch
+    import opencv_ar_amd as oa
+    cfg = H.synth_config(2)
+    names = ["2x2-01"]
+    n, chunk = 22, 4
+    tpls = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, x + ".png") for x in names])
+    cam = oa.default_camera(cfg.width, cfg.height)
+    frames = np.stack([H.synth_frame(cfg, 5 * f, names)[0] for f in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    det = oa.Detector(cfg.width, cfg.height, max_batch=n)
+    det.set_templates(tpls)
+    det.set_camera(cam)
+    m1, c1 = det.detect_device(d.data_ptr(), cfg.width, cfg.height, n, max_per_frame=8)
+    pipe = oa.Pipe(cfg.width, cfg.height, chunk_frames=chunk, n_contexts=3, gate_width=1)
+    pipe.set_templates(tpls)
+    pipe.set_camera(cam)
+    pipe.set_result_limit(8)
+    assert pipe.collect(chunk, 8) is None and pipe.in_flight() == 0
+    fb = cfg.width * cfg.height * 3
+    starts = list(range(0, n, chunk))
+    sub = 0
+    got = {}
+    while len(got) < len(starts):
+        while sub < len(starts):
+            cnt = min(chunk, n - starts[sub])
+            if not pipe.submit(d.data_ptr() + starts[sub] * fb, cfg.width, cfg.height, cnt, tag=1000 + sub):
+                assert pipe.in_flight() == 3      # busy: every context has a chunk
+                break
+            sub += 1
+        tag, m, c = pipe.collect(chunk, 8)
+        assert tag == 1000 + len(got)             # oldest first
+        got[tag - 1000] = (m, c)
+    assert pipe.in_flight() == 0
+    for k, s0 in enumerate(starts):
+        m, c = got[k]
+        assert c.tobytes() == c1[s0:s0 + len(c)].tobytes() and m.tobytes() == m1[s0:s0 + len(c)].tobytes()
+
+
 def test_pipe_tracks_streams_with_state_on_the_device():
     """ocvar_hip_pipe_track_device: 11 video streams, chunks of 4 going round 2 contexts, 3 time steps; every stream's markers
     of the previous step stay in device memory between the calls (ocvar_hip_enqueue_tracked).  Against the oracle run

@@ -35,3 +35,18 @@ for rep in range(3):
     best = max(best, n / dt)
     print(f"pipe: {n} frames, chunk {chunk}, {nctx} contexts, gate {gate}: {n / dt:.0f} frames/s ({1e3 * dt:.1f} ms), markers per frame {c.mean():.2f}", flush=True)
 print(f"best {best:.0f} frames/s")
+
+# streaming form: the pipeline never drains (chunks of `chunk` frames out of the same device array, round and round)
+pipe.set_result_limit(8)
+n_chunks, per = 48, n // chunk
+for rep in range(2):
+    t0 = time.perf_counter()
+    sub = done = 0
+    while done < n_chunks:
+        while sub < n_chunks and pipe.submit(d.data_ptr() + (sub % per) * chunk * W * Hh * 3, W, Hh, chunk, tag=sub):
+            sub += 1
+        tag, m, c = pipe.collect(chunk, 8)
+        assert tag == done and len(c) == chunk
+        done += 1
+    dt = time.perf_counter() - t0
+    print(f"pipe, streaming (submit / collect): {n_chunks} chunks of {chunk} frames, {nctx} contexts, gate {gate}: {n_chunks * chunk / dt:.0f} frames/s", flush=True)
