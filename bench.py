@@ -21,6 +21,13 @@ import time
 # it when it initialises, i.e. it must be in the environment before the first HIP call of the process (torch is imported
 # below).  The image exports it already; a caller's shell that dropped it gets it back here.  (One-rank runs do not need it.)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# The contexts' streams must not share hardware queues: the ROCm runtime multiplexes a process's HIP streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4), and with the null stream holding one of them the fourth context's kernels queue
+# behind another stream's (measured: 166 k frames/s instead of 200 k for four contexts on the runtime's default).  Read by the
+# runtime when it initialises, like the variable above; INTEGRATION.md tells C/C++ callers the same.  12: four context streams, the
+# null stream, and -- in multi-rank runs -- the gather stream and RCCL's own streams each get a queue (one-GPU run: 5 .. 12 queues all give
+# ~195 k; with RCCL initialised 6 / 8 / 12 queues give 155 / 182 / 195 k).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 import numpy as np
 
@@ -163,7 +170,8 @@ def main():
             det.set_tuning(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune})
         det.set_result_limit(8)   # what collect(8) takes: 3 MB instead of 24 MB of marker records per 2048-frame launch
         dets.append(det)
-        streams.append(torch.cuda.Stream())
+        # the context's own stream (ocvar_hip_enqueue with stream NULL); wrapped for the event waits of the gather below
+        streams.append(torch.cuda.ExternalStream(det.stream_ptr()))
     det = dets[0]
     # the batch is the distinct frames tiled, built on the device (the host only ever holds `uniq` frames)
     d_frames = torch.from_numpy(base).cuda().repeat((B + uniq - 1) // uniq, 1, 1, 1)[:B].contiguous()
@@ -204,7 +212,7 @@ def main():
         o = int(offs[i]) + skip
         if gather_done[buf] is not None:
             streams[i].wait_event(gather_done[buf])
-        dets[i].enqueue_device(d_frames.data_ptr() + o * frame_bytes, W, Hh, n, stream=streams[i].cuda_stream)
+        dets[i].enqueue_device(d_frames.data_ptr() + o * frame_bytes, W, Hh, n)
         if gathering:
             dets[i].results_to_device(d_res[buf].data_ptr() + o * GATHER_K * S.MARKER_BYTES,
                                       d_res[buf].data_ptr() + nbytes_m + 4 * o, streams[i].cuda_stream, per_frame=GATHER_K)
@@ -276,7 +284,7 @@ def main():
     # should be read against.  Reported separately, never mixed into `value`.
     iso = np.zeros(12, np.float64)
     for _ in range(3):
-        dets[0].enqueue_device(d_frames.data_ptr(), W, Hh, sub[0], stream=streams[0].cuda_stream)
+        dets[0].enqueue_device(d_frames.data_ptr(), W, Hh, sub[0])
         dets[0].collect(8)
         iso += dets[0].stage_ms() / 3
 

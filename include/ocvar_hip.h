@@ -135,6 +135,10 @@ int ocvar_hip_set_tuning(OcvarHip* ctx, int knob, int value);
 /* How the library was built: "... product(...)" or "... OCVAR_PROF(...)" -- bench.py prints it with its number. */
 const char* ocvar_hip_build_info(void);
 
+/* The context's own HIP stream (hipStream_t; what ocvar_hip_enqueue uses when its `stream` argument is NULL), for callers that
+ * order their own work or events against a batch. */
+void* ocvar_hip_stream(const OcvarHip* ctx);
+
 /* After ocvar_hip_enqueue: stream-ordered device-to-device copy of the batch's results into caller-owned device
  * buffers, d_markers [n_frames][OCVAR_MAX_MARKERS] and d_counts [n_frames] -- for callers that gather results
  * across GPUs (RCCL) before any host copy.  Does not wait; ocvar_hip_collect must still be called. */

@@ -26,7 +26,7 @@ HIP_SYMBOLS = [
     "ocvar_hip_pipe_detect_device", "ocvar_hip_pipe_track_device", "ocvar_hip_pipe_submit", "ocvar_hip_pipe_collect", "ocvar_hip_pipe_in_flight", "ocvar_hip_pipe_set_result_limit", "ocvar_hip_enqueue_tracked", "ocvar_hip_build_info", "ocvar_hip_set_tuning", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
     "ocvar_hip_detect_device", "ocvar_hip_enqueue", "ocvar_hip_collect", "ocvar_hip_detect_host", "ocvar_hip_find_squares",
     "ocvar_hip_debug_gray", "ocvar_hip_debug_binary", "ocvar_hip_debug_frame_quads", "ocvar_hip_debug_candidates",
-    "ocvar_hip_stage_ms", "ocvar_hip_stage_stamps", "ocvar_hip_counters", "ocvar_hip_results_to_device", "ocvar_hip_results_to_device_ex", "ocvar_hip_debug_calibrate",
+    "ocvar_hip_stage_ms", "ocvar_hip_stream", "ocvar_hip_stage_stamps", "ocvar_hip_counters", "ocvar_hip_results_to_device", "ocvar_hip_results_to_device_ex", "ocvar_hip_debug_calibrate",
 ]
 STAGE_NAMES = ["binarise_frames", "follow1_frames", "follow2_frames", "follow3_frames", "order_crops", "binarise_crops",
                "follow1_crops", "follow2_crops", "follow3_crops", "decode", "dedupe_pose", "batch_total"]
@@ -120,6 +120,8 @@ def hip_lib():
         lib.ocvar_hip_stage_ms.argtypes = [vp, vp, i]
         lib.ocvar_hip_counters.argtypes = [vp, vp, i]
         lib.ocvar_hip_stage_stamps.argtypes = [vp, vp, vp, i]
+        lib.ocvar_hip_stream.argtypes = [vp]
+        lib.ocvar_hip_stream.restype = vp
         lib.ocvar_hip_results_to_device.argtypes = [vp, vp, vp, vp]
         lib.ocvar_hip_results_to_device_ex.argtypes = [vp, vp, vp, i, vp]
         lib.ocvar_hip_debug_calibrate.argtypes = [vp, sz]
@@ -427,6 +429,10 @@ class Detector:
         ms = np.zeros(12, np.float32)
         k = self._lib.ocvar_hip_stage_ms(self._ctx, _ptr(ms), 12)
         return ms[:max(k, 0)]
+
+    def stream_ptr(self):
+        """the context's own hipStream_t as an integer (torch.cuda.ExternalStream(ptr) wraps it)"""
+        return self._lib.ocvar_hip_stream(self._ctx)
 
     def stage_stamps(self, ref_event):
         """the 13 stage boundaries of the last batch in ms after ref_event (a raw hipEvent_t, e.g. torch.cuda.Event(enable_timing=True).cuda_event)"""

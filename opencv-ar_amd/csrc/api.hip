@@ -246,6 +246,8 @@ static hipError_t gate_leave(OcvarGate* g, hipStream_t s) {
     return e;
 }
 
+extern "C" void* ocvar_hip_stream(const OcvarHip* c) { return c ? (void*)c->stream : nullptr; }
+
 extern "C" const char* ocvar_hip_last_error(const OcvarHip* c) { return c ? c->err.c_str() : "null context"; }
 extern "C" int ocvar_hip_capacity_flags(const OcvarHip* c) { return c ? c->capacity_flags : 0; }
 

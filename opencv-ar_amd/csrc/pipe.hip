@@ -9,6 +9,7 @@
 // context whose chunk is oldest.  Built on the public entry points only (ocvar_hip_create / enqueue / collect / gate).
 #include "ocvar_hip.h"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <new>
 #include <string>
 #include <vector>
@@ -42,6 +43,9 @@ extern "C" int ocvar_hip_pipe_create(OcvarPipe** out, int device, int max_width,
                                      int gate_width) {
     if (!out || chunk_frames < 1 || n_contexts < 1 || n_contexts > 16 || gate_width < 0) return OCVAR_E_ARG;
     *out = nullptr;
+    // every context's stream needs a hardware queue of its own ("Hardware queues"): effective only when this is the
+    // process's first HIP call -- a process that touched HIP earlier exports GPU_MAX_HW_QUEUES itself
+    (void)setenv("GPU_MAX_HW_QUEUES", n_contexts + 4 > 8 ? "20" : "8", 0);
     OcvarPipe* p = new (std::nothrow) OcvarPipe();
     if (!p) return OCVAR_E_HIP;
     *out = p;   // returned even on failure below so that the caller can read the error text, then destroy

@@ -59,6 +59,7 @@ extern "C" int ocvar_multi_create(OcvarMulti** out, const int* devices, int n_de
     // read by the ROCm runtime when it initialises.  Set here if the caller's environment lacks it -- effective only when
     // this is the process's first HIP call; a process that touched HIP earlier must export it itself.
     (void)setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+    (void)setenv("GPU_MAX_HW_QUEUES", "12", 0);   // (one stream per device here, but RCCL brings its own: see INTEGRATION.md, "Hardware queues")
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < n_devices) return OCVAR_E_NO_DEVICE;
     OcvarMulti* m = new OcvarMulti();

@@ -36,17 +36,22 @@ for rep in range(3):
     print(f"pipe: {n} frames, chunk {chunk}, {nctx} contexts, gate {gate}: {n / dt:.0f} frames/s ({1e3 * dt:.1f} ms), markers per frame {c.mean():.2f}", flush=True)
 print(f"best {best:.0f} frames/s")
 
-# streaming form: the pipeline never drains (chunks of `chunk` frames out of the same device array, round and round)
+# streaming form: the pipeline never drains (chunks out of the same device array, round and round).  Contexts that start together
+# stay in lock-step -- all in their binarise kernels, then all in their followers --, so the first n_contexts chunks are
+# (i + 1) / n_contexts of a chunk, as bench.py and ocvar_hip_pipe_detect_device stagger theirs.
 pipe.set_result_limit(8)
-n_chunks, per = 48, n // chunk
-for rep in range(2):
-    t0 = time.perf_counter()
-    sub = done = 0
-    while done < n_chunks:
-        while sub < n_chunks and pipe.submit(d.data_ptr() + (sub % per) * chunk * W * Hh * 3, W, Hh, chunk, tag=sub):
-            sub += 1
-        tag, m, c = pipe.collect(chunk, 8)
-        assert tag == done and len(c) == chunk
-        done += 1
-    dt = time.perf_counter() - t0
-    print(f"pipe, streaming (submit / collect): {n_chunks} chunks of {chunk} frames, {nctx} contexts, gate {gate}: {n_chunks * chunk / dt:.0f} frames/s", flush=True)
+n_chunks, per = int(os.environ.get("PIPE_CHUNKS", "48")), n // chunk
+for stagger in (False, True):
+    sizes = [chunk * (i + 1) // nctx if stagger and i < nctx else chunk for i in range(n_chunks)]
+    for rep in range(2):
+        t0 = time.perf_counter()
+        sub = done = 0
+        while done < n_chunks:
+            while sub < n_chunks and pipe.submit(d.data_ptr() + (sub % per) * chunk * W * Hh * 3, W, Hh, sizes[sub], tag=sub):
+                sub += 1
+            tag, m, c = pipe.collect(chunk, 8)
+            assert tag == done and len(c) == sizes[done]
+            done += 1
+        dt = time.perf_counter() - t0
+        print(f"pipe, streaming (submit / collect), first chunks {'staggered' if stagger else 'full'}: {n_chunks} chunks of <= {chunk} frames, {nctx} contexts, "
+              f"gate {gate}: {sum(sizes) / dt:.0f} frames/s", flush=True)
