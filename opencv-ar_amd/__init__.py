@@ -11,6 +11,11 @@ import os
 
 import numpy as np
 
+# Several contexts in flight need one hardware queue per stream ("Hardware queues"); the ROCm runtime reads this when
+# it initialises, so it only helps when this module is imported before anything touched the GPU -- callers that care set it
+# themselves, first thing (bench.py does).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 HIP_LIB = os.environ.get("OCVAR_HIP_LIB") or os.path.join(LIB_DIR, "libocvar_hip.so")   # (override: instrumented builds of tools/prof_tier2.py)

@@ -1307,6 +1307,7 @@ __global__ __launch_bounds__(256) void order_and_crops_kernel(Workspace ws) {
                     ws.rois_crop[r] = roi;
                     ws.best_crop[r] = ~0ull;
                     ws.crop_min_rest[r] = 0x7fffffff;
+                    ws.ring_crop[r] = 0;   // (ring_quads_kernel sets it where the crop's own frame border needs no walk)
                     for (int t = 0; t < ntx * nty; t++) {
                         TileDesc td;
                         td.roi = r; td.x0 = t % ntx; td.y0 = (t / ntx) * MARCH_CROP_ROWS;

@@ -5,6 +5,7 @@ running across its steps; a pipe call drains at its end).   python tools/pipe_ra
 import os
 import sys
 import time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # every context's stream on its own hardware queue; before torch touches HIP
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
