@@ -664,7 +664,12 @@ static void host_copy(uint8_t* dst, const uint8_t* src, size_t n) {
     const size_t per = ((n / nt) + 63) & ~(size_t)63;
     for (unsigned t = 1; t < nt; t++) {
         const size_t off = per * t, len = off >= n ? 0 : std::min(per, n - off);
-        if (len) th.emplace_back([=] { std::memcpy(dst + off, src + off, len); });
+        if (!len) continue;
+        try {
+            th.emplace_back([=] { std::memcpy(dst + off, src + off, len); });
+        } catch (...) {   // no thread to be had: this piece is copied here (nothing is thrown across the C ABI)
+            std::memcpy(dst + off, src + off, len);
+        }
     }
     std::memcpy(dst, src, std::min(per, n));
     for (auto& t : th) t.join();
@@ -770,7 +775,11 @@ extern "C" int ocvar_hip_detect_host(OcvarHip* c, uint8_t* h_bgr, int width, int
         grey_join();
         uint8_t* dst = h_bgr + off;
         const uint8_t* src = c->h_grey[k & 1];
-        grey_copier = std::thread([=] { host_copy(dst, src, len); });
+        try {
+            grey_copier = std::thread([=] { host_copy(dst, src, len); });
+        } catch (...) {
+            host_copy(dst, src, len);
+        }
         return hipSuccess;
     };
     HIP_TRY_HOST(upload(0));
