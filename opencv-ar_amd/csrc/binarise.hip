@@ -64,6 +64,17 @@ __device__ __forceinline__ unsigned dot2(us2 a, unsigned k, unsigned c) { return
 constexpr unsigned K2(unsigned lo, unsigned hi) { return lo | (hi << 16); }
 __device__ __forceinline__ unsigned alignb(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 __device__ __forceinline__ unsigned byte_of(unsigned v, int j) { return (v >> (8 * j)) & 255u; }
+__device__ __forceinline__ unsigned long long rotl64(unsigned long long v, unsigned s) { return s ? (v << s) | (v >> (64u - s)) : v; }
+// nib = 2 * nib + (floor(S / 65536) < byte B of w): the threshold test of one pixel, the operands picked by the instruction itself
+// (SDWA: the high word of S sign-extended, one byte of w) -- one compare and one add-with-carry, no operand to prepare.
+template <int B>
+__device__ __forceinline__ void push_bit(unsigned& nib, unsigned S, unsigned w) {
+    static_assert(B >= 0 && B < 4, "byte of a dword");
+    if constexpr (B == 0) asm("v_cmp_lt_i32_sdwa vcc, sext(%1), %2 src0_sel:WORD_1 src1_sel:BYTE_0\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nib) : "v"(S), "v"(w) : "vcc");
+    if constexpr (B == 1) asm("v_cmp_lt_i32_sdwa vcc, sext(%1), %2 src0_sel:WORD_1 src1_sel:BYTE_1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nib) : "v"(S), "v"(w) : "vcc");
+    if constexpr (B == 2) asm("v_cmp_lt_i32_sdwa vcc, sext(%1), %2 src0_sel:WORD_1 src1_sel:BYTE_2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nib) : "v"(S), "v"(w) : "vcc");
+    if constexpr (B == 3) asm("v_cmp_lt_i32_sdwa vcc, sext(%1), %2 src0_sel:WORD_1 src1_sel:BYTE_3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nib) : "v"(S), "v"(w) : "vcc");
+}
 
 
 
@@ -180,7 +191,9 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
             const uint2* s0 = reinterpret_cast<const uint2*>(rowbuf + flush_src);
             const uint2 a0 = s0[0], a1 = s0[1];       // row 2p: 16 bytes
             const uint2 b0 = s0[32], b1 = s0[33];     // row 2p+1 (one row = 64 dwords = 32 uint2)
-            uint8_t* dst = o.nbr + wave_uniform64(((long long)((yr_last >> 3) * (o.ns >> 4))) << 7) + flush_dst;
+            unsigned lane_off = flush_dst;
+            asm volatile("" : "+v"(lane_off));   // (scalar base + 32-bit lane offset: see fetch)
+            uint8_t* dst = o.nbr + wave_uniform64(((long long)((yr_last >> 3) * (o.ns >> 4))) << 7) + lane_off;
             typedef unsigned v4u __attribute__((ext_vector_type(4)));   // (non-temporal stores: written once, read much later)
             __builtin_nontemporal_store((v4u){a0.x, a0.y, a1.x, a1.y}, reinterpret_cast<v4u*>(dst));
             __builtin_nontemporal_store((v4u){b0.x, b0.y, b1.x, b1.y}, reinterpret_cast<v4u*>(dst) + 1);
@@ -215,19 +228,23 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
 
     // raw source words of virtual row v (3 dwords BGR / 1 dword grey for fast lanes, 4 pixels for edge lanes)
     struct Raw { unsigned d0, d1, d2; };
-    auto fetch = [&](int v, bool inside /* 0 <= v < sh is known */) -> Raw {
+    auto fetch = [&](int v, bool inside /* 0 <= v < sh is known; only asked for when the load plan holds (steady rows) */) -> Raw {
         Raw r = {0u, 0u, 0u};
         const uint8_t* row = src + wave_uniform64((long long)(inside ? v : reflect101(v, sh)) * src_stride);
-        if (plan) {
+        if (inside || plan) {
+            // (the lane's offset is made opaque per row: otherwise the compiler hoists base + offset out of the loop as a 64-bit
+            // pointer per lane -- two registers it then spills -- instead of the scalar-base + 32-bit-offset addressing form)
+            unsigned lane_off = goff;
+            asm volatile("" : "+v"(lane_off));
             if (BGR) {   // one unaligned global_load_dwordx3, non-temporal: a frame's rows stream through once and should not evict
                          // the mask lines the other contexts' border followers are walking in (+2 % with four contexts)
                 typedef unsigned __attribute__((aligned(1))) uu;
-                const uu* p = reinterpret_cast<const uu*>(row + goff);
+                const uu* p = reinterpret_cast<const uu*>(row + lane_off);
                 r.d0 = __builtin_nontemporal_load(p);
                 r.d1 = __builtin_nontemporal_load(p + 1);
                 r.d2 = __builtin_nontemporal_load(p + 2);
             } else {     // crops: ordinary loads -- the two concentric quads of a marker give two crops over nearly the same pixels
-                __builtin_memcpy(&r, row + goff, 4);
+                __builtin_memcpy(&r, row + lane_off, 4);
             }
             return r;
         }
@@ -279,26 +296,39 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     unsigned ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0;  // horizontal pyrDown sums of the last 5 rows (a | b<<16)
     unsigned prevP = 0;                      // previous pyramid row for the bottom border
     unsigned rAe = 0, rAo = 0, rBe = 0, rBo = 0;   // up-sampled pyramid rows q-2, q-1: even columns (r0|r2<<16), odd (r1|r3<<16)
-    // The last 8 (virtual) pyrUp rows, one pair of registers per pixel with a row per byte: wa[p] = rows vu-3 .. vu (newest in
-    // the high byte), wb[p] = rows vu-7 .. vu-4.  A new row is two byte permutes per pixel (no window of registers to shift),
-    // and the vertical 7-tap Gaussian of a pixel is two v_dot4_u32_u8.
+    // The last 8 (virtual) pyrUp rows, one pair of registers per pixel with a row per byte, kept as a RING: virtual row vu goes
+    // to byte vu & 3 of wa[p], which holds the current group of four rows (and, in the bytes not yet overwritten, the group
+    // before the previous one); wb[p] holds the previous group; when a group begins the two words change names (v_swap_b32).
+    // A new row is one byte permute per pixel (it overwrites a row that has left the window; nothing is shifted), the vertical
+    // 7-tap Gaussian of a pixel is two v_dot4_u32_u8 whose coefficient words are the kernel rotated to the ring's position,
+    // and the threshold's source byte (row vu-3) is picked by the compare itself.  In the steady rows the position is a
+    // compile-time constant (the loop is unrolled over 4 rows); the rows at the top and bottom of a unit compute selectors
+    // and coefficients on the scalar unit.  (An 8-row ring without the renaming needs the loop unrolled over 8 rows: with the
+    // two instances of this function in one kernel that was 52 KB of code and 30 % slower -- instruction cache.)
     unsigned wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
     unsigned m_prev = 0, u_prev = 0, x_prev = 0;   // mask of row y-1 still without its row below; what row y-1 gives to the row below it; its start nibbles
 
     // One source row.  S ("steady"): v lies where every range test below has a known outcome -- the rows it completes are
     // inside the work unit and away from the image's first and last rows -- so the tests (a scalar compare and branch
     // each, dozens per row) are compiled out; the rows at the top and bottom of a unit take the generic instance.
-    Raw nxt = fetch(v_first, false);
-    auto row = [&](const int v, auto steady_tag, auto parity_tag) {
+    Raw nxt = fetch(v_first, false), nxt2 = fetch(v_first + 1, false);
+    auto row = [&](const int v, auto steady_tag, auto parity_tag, auto ring_tag) {
         constexpr bool S = decltype(steady_tag)::value;
         constexpr int PAR = decltype(parity_tag)::value;   // 1: v is odd, 2: v is even, 0: not known at compile time
+        constexpr int VM = decltype(ring_tag)::value;      // v & 3 of an even steady row (the ring position follows from it), -1: not known
         const Raw cur = nxt;
-        if (S || v < v_last) nxt = fetch(v + 1, S);  // issue the next row's loads before this row's arithmetic
+        nxt = nxt2;
+        // issue the loads of the row after the next before this row's arithmetic: two rows in flight per wave -- with one, the
+        // ~6 K resident waves have 4.7 MB under way, which at the latency of a loaded memory system caps the kernel near 4 TB/s
+        if (S || v + 1 < v_last) nxt2 = fetch(v + 2, S);
         unsigned g = to_grey(cur);
-        if (plan && permuted) g = __builtin_amdgcn_perm(g, g, gsel);
+        if ((S || plan) && permuted) g = __builtin_amdgcn_perm(g, g, gsel);
         if (BGR && o.gray && out_lane && (S || (v >= Y0 && v < Y1))) {  // rows [Y0,Y1) are real rows, each loaded exactly once
-            uint8_t* q = o.gray + wave_uniform64((long long)v * o.gray_stride) + out_off;
-            if (gray_dword) __builtin_nontemporal_store(g, reinterpret_cast<unsigned*>(q));
+            unsigned lane_off = out_off;
+            asm volatile("" : "+v"(lane_off));   // (see fetch)
+            uint8_t* q = o.gray + wave_uniform64((long long)v * o.gray_stride) + lane_off;
+            // (steady rows: the plane's stride is a multiple of 4, so the width is, and every output lane holds 4 columns of it)
+            if (S || gray_dword) __builtin_nontemporal_store(g, reinterpret_cast<unsigned*>(q));
             else
                 for (int j = 0; j < 4; j++)
                     if (c0 + j < sw) q[j] = (uint8_t)byte_of(g, j);
@@ -362,42 +392,75 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                 // rows above 0 / below sh-1 replicate row 0 / sh-1; one more virtual row flushes the last mask row
                 const int vlo = (!S && u == 0) ? -3 : u, vhi = (!S && u == sh - 1) ? sh + 3 : u;
                 for (int vu = vlo; vu <= vhi; vu++) {
-                    {
-                        const unsigned U4 = as_u32(Ue) | (as_u32(Uo) << 8);   // u0 u1 u2 u3 as bytes (each <= 255)
+                    const int slot = VM >= 0 ? ((VM + par) & 3) : (vu & 3);   // steady rows: vu = u = v - 4 + par
+                    if (slot == 0) {   // a new group of four rows: the words change names
+                        if constexpr (VM >= 0) {
 #pragma unroll
-                        for (int p = 0; p < 4; p++) {
-                            wb[p] = __builtin_amdgcn_perm(wa[p], wb[p], 0x04030201u);             // drop the oldest row, take wa's oldest
-                            wa[p] = __builtin_amdgcn_perm(U4, wa[p], 0x04030201u + ((unsigned)p << 24));   // ... and pixel p of the new row
+                            for (int p = 0; p < 4; p++) asm("v_swap_b32 %0, %1" : "+v"(wa[p]), "+v"(wb[p]));
+                        } else {
+#pragma unroll
+                            for (int p = 0; p < 4; p++) { const unsigned t = wa[p]; wa[p] = wb[p]; wb[p] = t; }
                         }
                     }
-                    const int y = vu - 3;   // the window now holds pyrUp rows y-3 .. y+3
+                    {   // pixel p of the new row (u0, u2 = bytes 0, 2 of Ue; u1, u3 of Uo: each <= 255) into byte `slot` of wa[p]
+                        const unsigned kb = 8u * (unsigned)slot, keep = 0x03020100u & ~(0xffu << kb);
+                        const unsigned s4 = keep | (4u << kb), s6 = keep | (6u << kb);
+                        wa[0] = __builtin_amdgcn_perm(as_u32(Ue), wa[0], s4);
+                        wa[1] = __builtin_amdgcn_perm(as_u32(Uo), wa[1], s4);
+                        wa[2] = __builtin_amdgcn_perm(as_u32(Ue), wa[2], s6);
+                        wa[3] = __builtin_amdgcn_perm(as_u32(Uo), wa[3], s6);
+                    }
+                    const int y = vu - 3;   // the ring now holds pyrUp rows y-3 .. y+3 (and row vu-7: weight 0)
                     if (!S && (y < Y0 - 1 || y > Y1 || y < 0)) continue;
                     unsigned nib = 0;
                     if (S || (y >= 1 && y <= sh - 2)) {
-                        // 7x7 Gaussian, vertical pass first: [8 28 56 72 56 28 8] over rows y-3 .. y+3 = bytes 1..3 of wb, 0..3 of wa
+                        // 7x7 Gaussian, vertical pass first: [8 28 56 72 56 28 8] over rows y-3 .. y+3.  Seen as eight slots (wa's bytes,
+                        // then wb's) with the newest row in slot 7 the weights would be 0 8 28 56 | 72 56 28 8; the newest row is in
+                        // slot `slot` of wa: that word pair rotated by whole bytes.
                         // (<= 256*255: the sums fit 16 bits and are packed in pairs for the horizontal pass)
+                        const unsigned long long KW = rotl64(0x081C3848381C0800ull, 8u * (unsigned)((slot + 1) & 7));
+                        const unsigned kwa = (unsigned)KW, kwb = (unsigned)(KW >> 32);
                         unsigned V[4];
 #pragma unroll
-                        for (int p = 0; p < 4; p++) V[p] = dot4(wa[p], 72u | (56u << 8) | (28u << 16) | (8u << 24), dot4(wb[p], (8u << 8) | (28u << 16) | (56u << 24), 0u));
-                        const us2 Ve = as_us2(V[0] | (V[2] << 16)), Vo = as_us2(V[1] | (V[3] << 16));
-                        // horizontal pass: 16-bit column sums of this lane (V0..V3 = Ve.x Vo.x Ve.y Vo.y), the lane to the
-                        // left (l) and to the right (r), two taps per v_dot2_u32_u16.  The accumulator starts at the
-                        // rounding constant minus 8<<16:  src - mean > -8  <=>  sum + 32768 - (8<<16) < src<<16
-                        const us2 Vel = as_us2(up1(as_u32(Ve))), Vol = as_us2(up1(as_u32(Vo)));
-                        const us2 Ver = as_us2(down1(as_u32(Ve))), Vor = as_us2(down1(as_u32(Vo)));
+                        for (int p = 0; p < 4; p++) V[p] = dot4(wa[p], kwa, dot4(wb[p], kwb, 0u));
+                        const us2 Va = as_us2(V[0] | (V[1] << 16)), Vb = as_us2(V[2] | (V[3] << 16));
+                        // horizontal pass: 16-bit column sums of this lane (Va = V0 V1, Vb = V2 V3), the lane to the left (l) and to
+                        // the right (r), two taps per v_dot2_u32_u16 -- with neighbouring columns paired every pixel's 7 taps are 4
+                        // instructions.  The accumulator starts at the rounding constant minus 8<<16:
+                        // src - mean > -8  <=>  sum + 32768 - (8<<16) < src<<16
+                        const us2 Val = as_us2(up1(as_u32(Va))), Vbl = as_us2(up1(as_u32(Vb)));     // V-4 V-3, V-2 V-1
+                        const us2 Var = as_us2(down1(as_u32(Va))), Vbr = as_us2(down1(as_u32(Vb))); // V4 V5, V6 V7
                         const unsigned C0 = 32768u - (8u << 16);
-                        const unsigned S0 = dot2(Vol, K2(8, 56), dot2(Vel, K2(0, 28), dot2(Ve, K2(72, 28), dot2(Vo, K2(56, 8), C0))));
-                        const unsigned S1 = dot2(Vel, K2(0, 8), dot2(Vol, K2(0, 28), dot2(Ve, K2(56, 56), dot2(Vo, K2(72, 28), dot2(Ver, K2(8, 0), C0)))));
-                        const unsigned S2 = dot2(Vol, K2(0, 8), dot2(Ve, K2(28, 72), dot2(Vo, K2(56, 56), dot2(Ver, K2(28, 0), dot2(Vor, K2(8, 0), C0)))));
-                        const unsigned S3 = dot2(Ve, K2(8, 56), dot2(Vo, K2(28, 72), dot2(Ver, K2(56, 8), dot2(Vor, K2(28, 0), C0))));
-                        // pyrUp row y itself -- byte 0 of wa -- is the threshold's source; nib = 2 * nib + (S < src << 16), pixel 3
-                        // first: one compare and one add-with-carry per pixel
-#define OCVAR_PUSH_BIT(S, P) asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nib) : "v"(S), "v"(__builtin_amdgcn_perm(wa[P], wa[P], 0x0c000c0cu)) : "vcc")
-                        OCVAR_PUSH_BIT(S3, 3);
-                        OCVAR_PUSH_BIT(S2, 2);
-                        OCVAR_PUSH_BIT(S1, 1);
-                        OCVAR_PUSH_BIT(S0, 0);
+                        const unsigned S0 = dot2(Val, K2(0, 8), dot2(Vbl, K2(28, 56), dot2(Va, K2(72, 56), dot2(Vb, K2(28, 8), C0))));
+                        const unsigned S1 = dot2(Vbl, K2(8, 28), dot2(Va, K2(56, 72), dot2(Vb, K2(56, 28), dot2(Var, K2(8, 0), C0))));
+                        const unsigned S2 = dot2(Vbl, K2(0, 8), dot2(Va, K2(28, 56), dot2(Vb, K2(72, 56), dot2(Var, K2(28, 8), C0))));
+                        const unsigned S3 = dot2(Va, K2(8, 28), dot2(Vb, K2(56, 72), dot2(Var, K2(56, 28), dot2(Vbr, K2(8, 0), C0))));
+                        // pyrUp row y itself -- slot (slot - 3) & 7 of the eight -- is the threshold's source; nib = 2 * nib + (S < src << 16),
+                        // pixel 3 first: one compare and one add-with-carry per pixel
+                        const int ts = (slot + 5) & 7;
+                        if constexpr (VM >= 0) {
+                            constexpr int TS = ((VM & 3) + 5) & 7;   // par = 0; par = 1 is the next slot
+                            if (par == 0) {
+                                push_bit<TS & 3>(nib, S3, TS < 4 ? wa[3] : wb[3]);
+                                push_bit<TS & 3>(nib, S2, TS < 4 ? wa[2] : wb[2]);
+                                push_bit<TS & 3>(nib, S1, TS < 4 ? wa[1] : wb[1]);
+                                push_bit<TS & 3>(nib, S0, TS < 4 ? wa[0] : wb[0]);
+                            } else {
+                                constexpr int T1 = (TS + 1) & 7;
+                                push_bit<T1 & 3>(nib, S3, T1 < 4 ? wa[3] : wb[3]);
+                                push_bit<T1 & 3>(nib, S2, T1 < 4 ? wa[2] : wb[2]);
+                                push_bit<T1 & 3>(nib, S1, T1 < 4 ? wa[1] : wb[1]);
+                                push_bit<T1 & 3>(nib, S0, T1 < 4 ? wa[0] : wb[0]);
+                            }
+                        } else {
+                            const unsigned tsel = 0x0c000c0cu | ((unsigned)ts << 16);   // byte ts of (wb : wa) into byte 2, zeros elsewhere
+#define OCVAR_PUSH_BIT(S, P) asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nib) : "v"(S), "v"(__builtin_amdgcn_perm(wb[P], wa[P], tsel)) : "vcc")
+                            OCVAR_PUSH_BIT(S3, 3);
+                            OCVAR_PUSH_BIT(S2, 2);
+                            OCVAR_PUSH_BIT(S1, 1);
+                            OCVAR_PUSH_BIT(S0, 0);
 #undef OCVAR_PUSH_BIT
+                        }
                         nib &= colmask;
                     }
                     // Row y's window -> table: its share of the masks of rows y-1, y, y+1 and its start nibbles.
@@ -420,7 +483,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                     // Hole: background pixel whose W and N are foreground -- and E or NE foreground (if both are background they
                     // belong to the same 4-connected background region and NE comes earlier).
                     if ((!S && (y < Y0 || y >= Y1)) || __ballot(st != 0) == 0) continue;
-#pragma unroll
+#pragma nounroll   // (rare rows, and the steady loop holds eight copies of this: kept small)
                     for (int j = 0; j < 4; j++) {
                         const int type = ((st >> j) & 1u) ? 0 : ((st >> (8 + j)) & 1u) ? 1 : -1;
                         const unsigned long long mask = __ballot(type >= 0);
@@ -439,19 +502,32 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     // steady rows: v and v+1 are real rows of this unit ([Y0, Y1), v+1 <= sh-1), and the rows an even v completes -- pyrUp
     // rows v-4, v-3, threshold rows v-7, v-6, mask rows v-8, v-7 -- are inside the unit, at least one row away from the
     // image's top and bottom (no replicated pyrUp rows, no zeroed contour-frame rows) and not the unit's last mask row
-    const int vs0 = (Y0 + 8 > 8 ? Y0 + 8 : 8) | 1, vs1 = Y1 - 1 < sh - 2 ? Y1 - 1 : sh - 2;   // (vs0 odd: steady rows run in pairs)
+    // -- and the unit has the load plan and whole-dword grey stores (else no row is steady: the steady instance of the row body
+    // carries neither the byte-wise loads of images narrower than 32 columns nor byte-wise grey stores)
+    const bool steady_ok = plan && (!(BGR && o.gray) || (o.gray_stride & 3) == 0);
+    const int vs0 = (Y0 + 8 > 8 ? Y0 + 8 : 8) | 1, vs1 = !steady_ok ? -1 : Y1 - 1 < sh - 3 ? Y1 - 1 : sh - 3;   // (vs0 odd: steady rows run in pairs; v + 2 is a real row: prefetched unreflected)
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     using P2 = std::integral_constant<int, 2>;
+    using RX = std::integral_constant<int, -1>;   // ring position not known at compile time
     int v = v_first;
 #pragma nounroll
-    for (int phase = 0; phase < 2; phase++) {   // generic rows, steady pairs, generic rows: one copy of each instance
+    for (int phase = 0; phase < 2; phase++) {   // generic rows, steady rows, generic rows: one copy of each instance
         const int end = phase == 0 ? (vs0 <= v_last + 1 ? vs0 : v_last + 1) : v_last + 1;
-        for (; v < end; v++) row(v, std::false_type(), P0());
+        for (; v < end; v++) row(v, std::false_type(), P0(), RX());
         if (phase == 0)
-            for (; v + 1 <= vs1; v += 2) {
-                row(v, std::true_type(), P1());
-                row(v + 1, std::true_type(), P2());
+            while (v + 1 <= vs1) {
+                if ((v & 3) == 1 && v + 3 <= vs1) {   // four rows with the ring's position known: the hot loop
+                    row(v, std::true_type(), P1(), RX());
+                    row(v + 1, std::true_type(), P2(), std::integral_constant<int, 2>());
+                    row(v + 2, std::true_type(), P1(), RX());
+                    row(v + 3, std::true_type(), P2(), std::integral_constant<int, 0>());
+                    v += 4;
+                } else {                               // a pair before the first or after the last group of four
+                    row(v, std::true_type(), P1(), RX());
+                    row(v + 1, std::true_type(), P2(), RX());
+                    v += 2;
+                }
             }
     }
     flush();
