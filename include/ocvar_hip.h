@@ -197,6 +197,8 @@ int ocvar_hip_find_squares(OcvarHip* ctx, const uint8_t* h_gray, int width, int 
 /* Parity hooks on the state left by the last detect/enqueue+collect call. */
 int ocvar_hip_debug_gray(OcvarHip* ctx, int frame, uint8_t* h_gray /* width*height */);
 int ocvar_hip_debug_binary(OcvarHip* ctx, int frame, uint8_t* h_bin /* (w&~1)*(h&~1), values 0/255 */);
+/* the frame pass's 8-neighbour masks, untiled: bit s of pixel (x,y) = the neighbour in direction s (0..7 = E,NE,N,NW,W,SW,S,SE) is set */
+int ocvar_hip_debug_masks(OcvarHip* ctx, int frame, uint8_t* h_masks /* (w&~1)*(h&~1) */);
 int ocvar_hip_debug_frame_quads(OcvarHip* ctx, int frame, int* quads /* OCVAR_MAX_QUADS*8 */, int* n_quads);
 int ocvar_hip_debug_candidates(OcvarHip* ctx, int frame, OcvarCandidate* cands, int max_cands, int* n_cands);
 

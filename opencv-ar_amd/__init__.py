@@ -30,7 +30,7 @@ HIP_SYMBOLS = [
     "ocvar_hip_pipe_create", "ocvar_hip_pipe_destroy", "ocvar_hip_pipe_last_error", "ocvar_hip_pipe_set_templates", "ocvar_hip_pipe_set_camera",
     "ocvar_hip_pipe_detect_device", "ocvar_hip_pipe_track_device", "ocvar_hip_pipe_submit", "ocvar_hip_pipe_collect", "ocvar_hip_pipe_in_flight", "ocvar_hip_pipe_set_result_limit", "ocvar_hip_enqueue_tracked", "ocvar_hip_build_info", "ocvar_hip_set_tuning", "ocvar_hip_destroy", "ocvar_hip_last_error", "ocvar_hip_set_templates", "ocvar_hip_set_camera",
     "ocvar_hip_detect_device", "ocvar_hip_enqueue", "ocvar_hip_collect", "ocvar_hip_detect_host", "ocvar_hip_find_squares",
-    "ocvar_hip_debug_gray", "ocvar_hip_debug_binary", "ocvar_hip_debug_frame_quads", "ocvar_hip_debug_candidates",
+    "ocvar_hip_debug_gray", "ocvar_hip_debug_binary", "ocvar_hip_debug_masks", "ocvar_hip_debug_frame_quads", "ocvar_hip_debug_candidates",
     "ocvar_hip_stage_ms", "ocvar_hip_stream", "ocvar_hip_stage_stamps", "ocvar_hip_counters", "ocvar_hip_results_to_device", "ocvar_hip_results_to_device_ex", "ocvar_hip_debug_calibrate",
 ]
 STAGE_NAMES = ["binarise_frames", "follow1_frames", "follow2_frames", "follow3_frames", "order_crops", "binarise_crops",
@@ -120,6 +120,7 @@ def hip_lib():
         lib.ocvar_hip_find_squares.argtypes = [vp, vp, i, i, i, vp, i, vp]
         lib.ocvar_hip_debug_gray.argtypes = [vp, i, vp]
         lib.ocvar_hip_debug_binary.argtypes = [vp, i, vp]
+        lib.ocvar_hip_debug_masks.argtypes = [vp, i, vp]
         lib.ocvar_hip_debug_frame_quads.argtypes = [vp, i, vp, vp]
         lib.ocvar_hip_debug_candidates.argtypes = [vp, i, vp, i, vp]
         lib.ocvar_hip_stage_ms.argtypes = [vp, vp, i]
@@ -416,6 +417,12 @@ class Detector:
     def debug_binary(self, frame, width, height):
         out = np.zeros((height & -2, width & -2), np.uint8)
         self._check(self._lib.ocvar_hip_debug_binary(self._ctx, frame, _ptr(out)), "debug_binary")
+        return out
+
+    def debug_masks(self, frame, width, height):
+        """8-neighbour masks of the frame pass (bit s: the neighbour in direction s = E,NE,N,NW,W,SW,S,SE is set), untiled."""
+        out = np.zeros((height & -2, width & -2), np.uint8)
+        self._check(self._lib.ocvar_hip_debug_masks(self._ctx, frame, _ptr(out)), "debug_masks")
         return out
 
     def debug_frame_quads(self, frame):

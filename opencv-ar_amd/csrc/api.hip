@@ -855,6 +855,18 @@ extern "C" int ocvar_hip_debug_binary(OcvarHip* c, int frame, uint8_t* h) {
     return OCVAR_OK;
 }
 
+extern "C" int ocvar_hip_debug_masks(OcvarHip* c, int frame, uint8_t* h) {
+    if (!c || !h || frame < 0 || frame >= c->ws.n_frames) return OCVAR_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int sw = c->ws.sw, sh = c->ws.sh, ns = c->ws.ns;
+    const size_t bytes = (size_t)nbr_plane_bytes(ns, sh);
+    std::vector<uint8_t> nbr(bytes);
+    HIP_TRY(c, hipMemcpy(nbr.data(), c->ws.nbr_frame + (size_t)frame * bytes, bytes, hipMemcpyDeviceToHost));
+    for (int y = 0; y < sh; y++)
+        for (int x = 0; x < sw; x++) h[(size_t)y * sw + x] = nbr[(size_t)nbr_addr(x, y, ns)];
+    return OCVAR_OK;
+}
+
 extern "C" int ocvar_hip_debug_frame_quads(OcvarHip* c, int frame, int* quads, int* n_quads) {
     if (!c || !quads || !n_quads || frame < 0 || frame >= c->ws.n_frames) return OCVAR_E_ARG;
     HIP_TRY(c, hipSetDevice(c->device));

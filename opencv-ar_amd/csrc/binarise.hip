@@ -22,6 +22,13 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef OCVAR_WAVES_F
+#define OCVAR_WAVES_F 5   // waves per SIMD the frame kernel is compiled for (register budget 512 / n, in eights)
+#endif
+#ifndef OCVAR_WAVES_C
+#define OCVAR_WAVES_C 5   // ... and the crop kernel
+#endif
+
 namespace ocvar {
 
 constexpr int SV = MARCH_STRIP;  // output columns per strip
@@ -43,6 +50,12 @@ __device__ __forceinline__ long long wave_uniform64(long long v) {
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
+
+// buffer resource over [p, p + bytes): raw (stride 0), 32-bit data format -- the addressing mode of the row loads and stores
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+constexpr int BUF_NT = 2;   // cache policy "non-temporal" of the buffer builtins
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -76,7 +89,15 @@ __device__ __forceinline__ void push_bit(unsigned& nib, unsigned S, unsigned w) 
     if constexpr (B == 3) asm("v_cmp_lt_i32_sdwa vcc, sext(%1), %2 src0_sel:WORD_1 src1_sel:BYTE_3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nib) : "v"(S), "v"(w) : "vcc");
 }
 
-
+// nib = (floor(S / 65536) < byte B of w): the first pixel's test starts the nibble (no register to clear)
+template <int B>
+__device__ __forceinline__ void first_bit(unsigned& nib, unsigned S, unsigned w) {
+    static_assert(B >= 0 && B < 4, "byte of a dword");
+    if constexpr (B == 0) asm("v_cmp_lt_i32_sdwa vcc, sext(%1), %2 src0_sel:WORD_1 src1_sel:BYTE_0\n\tv_cndmask_b32_e64 %0, 0, 1, vcc" : "=v"(nib) : "v"(S), "v"(w) : "vcc");
+    if constexpr (B == 1) asm("v_cmp_lt_i32_sdwa vcc, sext(%1), %2 src0_sel:WORD_1 src1_sel:BYTE_1\n\tv_cndmask_b32_e64 %0, 0, 1, vcc" : "=v"(nib) : "v"(S), "v"(w) : "vcc");
+    if constexpr (B == 2) asm("v_cmp_lt_i32_sdwa vcc, sext(%1), %2 src0_sel:WORD_1 src1_sel:BYTE_2\n\tv_cndmask_b32_e64 %0, 0, 1, vcc" : "=v"(nib) : "v"(S), "v"(w) : "vcc");
+    if constexpr (B == 3) asm("v_cmp_lt_i32_sdwa vcc, sext(%1), %2 src0_sel:WORD_1 src1_sel:BYTE_3\n\tv_cndmask_b32_e64 %0, 0, 1, vcc" : "=v"(nib) : "v"(S), "v"(w) : "vcc");
+}
 
 // ---- neighbour masks and border starts by table ---------------------------------------------------------------------
 // A lane's 4 threshold bits of one row plus the bits next to them form a 7-bit window: bit 0 = column c0-1 (the left
@@ -110,6 +131,9 @@ __device__ __forceinline__ uint4 mask_table_entry(unsigned w) {
     return t;
 }
 
+// table index (march_unit: bits 0..3 own pixels, bit 4 the left lane's pixel 3, bits 5, 6 the right lane's pixels 0, 1) -> window
+__device__ __forceinline__ unsigned table_window(unsigned i) { return ((i >> 4) & 1u) | ((i & 15u) << 1) | ((i >> 5) << 5); }
+
 struct MarchOut {
     uint8_t* gray;          // frame mode: grey plane of this frame (stride gray_stride), else null
     long long gray_stride;
@@ -137,9 +161,22 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     const bool needed = !EDGE || (c0 + 3 >= -16 && c0 < sw + 16);  // beyond every halo: never consumed
     const bool fast = !EDGE || (c0 >= 0 && c0 + 3 < sw);
     const bool aligned = BGR ? ((src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) : true;
-    const bool left_edge = EDGE && strip == 0;     // lanes 0..HL-1 hold virtual columns -4*HL..-1
-    const int L1 = (sw - 1 - XS) >> 2, j1 = (sw - 1 - XS) & 3;  // lane / byte of column sw-1
-    const bool right_edge = EDGE && L1 <= 63;      // some lane of the wave holds columns >= sw
+    // (wave-uniform flags as scalars: left as they are the compiler keeps them as lane masks and re-derives their negations with
+    // vector instructions in every row)
+    // The filters' border rules at the image's left and right edge are byte selections in the one or two lanes that hold the edge
+    // columns; every lane carries its selectors (the identity elsewhere), so the row body needs no wave-uniform "this strip touches
+    // an edge" tests -- as flags those cost scalar registers the kernel does not have, and a handful of vector instructions per row
+    // to re-derive their negations.  (v_perm_b32: bytes 0..3 = the second operand, 4..7 = the first.)
+    constexpr unsigned SEL_ID = 0x03020100u;
+    // pyrUp's right border, "pyramid column pw stands for column pw-1", on the lane's pair (P[k0], P[k0+1]) with the left lane's pair as first operand
+    const unsigned selP = !EDGE ? SEL_ID : k0 + 1 == pw ? 0x01000100u : k0 == pw ? 0x03020706u : SEL_ID;
+    // BORDER_REPLICATE of the 7x7 Gaussian, applied to the vertical sums (a replicated column's sums are the edge column's): the lane
+    // that holds column 0 takes (V0, V0) for what it would receive from its left neighbour; the lane that holds column sw-1 (its
+    // pixel 1 or 3: sw is even) first overwrites its own pair (V2, V3) when those lie beyond the edge, then takes its last real
+    // column for what it would receive from the right.
+    const unsigned selL = EDGE && c0 == 0 ? 0x05040504u : SEL_ID;
+    const unsigned selB = EDGE && c0 + 2 == sw ? 0x07060706u : SEL_ID;
+    const unsigned selR = EDGE && c0 < sw && c0 + 4 >= sw ? 0x07060706u : SEL_ID;
     const bool gray_dword = o.gray && (o.gray_stride & 3) == 0 && (!EDGE || c0 + 3 < sw);
     // reflected source columns of the lanes that straddle an image edge (BORDER_REFLECT_101)
     int xr0 = 0, xr1 = 0, xr2 = 0, xr3 = 0;
@@ -165,15 +202,29 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         else goff = (unsigned)c0;
     }
     goff *= BGR ? 3u : 1u;
-    const bool permuted = left_edge || right_edge;   // wave-uniform: some lane of this strip holds reflected columns
     // per-lane byte offsets (unsigned: the row bases are wave-uniform, so loads/stores can use the SGPR-base + 32-bit VGPR offset form)
     const unsigned src_off = fast ? (unsigned)(c0 * (BGR ? 3 : 1)) : 0u;
-    const unsigned out_off = out_lane ? (unsigned)c0 : 0u;
-    const unsigned rmask = lane == 63 - HR ? 1u : 3u;   // the last output lane's x+2 bit (row above) is not computed
+    // Rows are addressed through buffer resources: base in four SGPRs, the row's byte offset in one SGPR (one s_mul per row), the
+    // lane's offset in a loop-invariant VGPR -- no 64-bit address arithmetic, no per-lane pointers to keep or spill.  A lane that
+    // must not store gets an offset beyond the resource's size: the hardware drops its store, so the grey and mask stores need
+    // no EXEC mask and the row body stays one basic block.
+    constexpr unsigned OOB = 0x80000000u;   // >= every resource size below (+ 16 does not wrap)
+    const __amdgpu_buffer_rsrc_t src_rs = make_rsrc(src, 0x7fffffffu);
+    const __amdgpu_buffer_rsrc_t gray_rs = make_rsrc(o.gray, o.gray ? (unsigned)(o.gray_stride * sh) : 0u);
+    const __amdgpu_buffer_rsrc_t nbr_rs = make_rsrc(o.nbr, (unsigned)nbr_plane_bytes(o.ns, sh));
+    const unsigned out_off = out_lane ? (unsigned)c0 : OOB;
+    const unsigned rmask4 = lane == 63 - HR ? 0x10u : 0x30u;   // the last output lane's x+2 bit (row above) is not computed
+    unsigned bit7;   // (a constant in a register, opaque to the compiler: then the AND below folds into the DPP move -- DPP operands cannot be literals)
+    asm("v_mov_b32 %0, 0x80" : "=v"(bit7));
     unsigned colmask = 0;  // which of the lane's 4 columns lie inside cvFindContours' zeroed frame
     for (int j = 0; j < 4; j++) colmask |= (!EDGE || (c0 + j >= 1 && c0 + j <= sw - 2)) ? (1u << j) : 0u;
-    unsigned pxsel = 0;    // bits j and 8+j: the lane's pixel j is an output pixel of this strip (outer / hole start nibbles)
-    for (int j = 0; j < 4; j++) pxsel |= (out_lane && (!EDGE || c0 + j < sw)) ? (0x101u << j) : 0u;
+    // Which pixels may yield border starts: the output lanes' (inside the image).  Strips away from the edges: all four pixels of
+    // lanes HL .. 63-HR, a constant lane mask applied to the ballots (scalar); strips at an edge: per lane, bits j and 8+j (outer /
+    // hole start nibbles) of a register.
+    constexpr unsigned long long OUT_LANES = (~0ull << HL) & (~0ull >> HR);
+    unsigned pxsel = 0;
+    if (EDGE)
+        for (int j = 0; j < 4; j++) pxsel |= (out_lane && c0 + j < sw) ? (0x101u << j) : 0u;
 
     // Mask rows are collected in LDS, 8 rows at a time, and written as whole 16x8-pixel tiles (128 contiguous bytes, 32
     // per lane) -- a row at a time would be 16-byte pieces of 15 different cache lines per wave, and on this hardware a
@@ -184,19 +235,17 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     const int tile_x = strip * (SV / 16) + (lane >> 2);          // lanes 0..59: tile of this strip, 4 lanes per tile
     const bool flush_lane = lane < 4 * (SV / 16) && tile_x * 16 < o.ns;
     const unsigned flush_src = (unsigned)(2 * (lane & 3)) * 64u + (unsigned)(HL + 4 * (lane >> 2));   // dword index in rowbuf: row 2p, first lane of the tile
-    const unsigned flush_dst = ((unsigned)tile_x << 7) + (unsigned)(2 * (lane & 3)) * 16u;           // byte offset inside a tile row group
+    const unsigned flush_dst = flush_lane ? ((unsigned)tile_x << 7) + (unsigned)(2 * (lane & 3)) * 16u : OOB;   // byte offset inside a tile row group
     auto flush_rows = [&](int yr_last) {   // yr_last: last row written; its group is complete or the unit ends
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        if (flush_lane) {
-            const uint2* s0 = reinterpret_cast<const uint2*>(rowbuf + flush_src);
+        {
+            const uint2* s0 = reinterpret_cast<const uint2*>(rowbuf + flush_src);   // (lanes 60..63 read past the tiles, at most two dwords past this wave's rows: their store is dropped)
             const uint2 a0 = s0[0], a1 = s0[1];       // row 2p: 16 bytes
             const uint2 b0 = s0[32], b1 = s0[33];     // row 2p+1 (one row = 64 dwords = 32 uint2)
-            unsigned lane_off = flush_dst;
-            asm volatile("" : "+v"(lane_off));   // (scalar base + 32-bit lane offset: see fetch)
-            uint8_t* dst = o.nbr + wave_uniform64(((long long)((yr_last >> 3) * (o.ns >> 4))) << 7) + lane_off;
+            const int so = wave_uniform(((yr_last >> 3) * (o.ns >> 4)) << 7);
             typedef unsigned v4u __attribute__((ext_vector_type(4)));   // (non-temporal stores: written once, read much later)
-            __builtin_nontemporal_store((v4u){a0.x, a0.y, a1.x, a1.y}, reinterpret_cast<v4u*>(dst));
-            __builtin_nontemporal_store((v4u){b0.x, b0.y, b1.x, b1.y}, reinterpret_cast<v4u*>(dst) + 1);
+            __builtin_amdgcn_raw_buffer_store_b128((v4u){a0.x, a0.y, a1.x, a1.y}, nbr_rs, (int)flush_dst, so, BUF_NT);
+            __builtin_amdgcn_raw_buffer_store_b128((v4u){b0.x, b0.y, b1.x, b1.y}, nbr_rs, (int)flush_dst, so + 16, BUF_NT);   // (+16 on the scalar side: no second offset register)
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     };
@@ -230,24 +279,20 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     struct Raw { unsigned d0, d1, d2; };
     auto fetch = [&](int v, bool inside /* 0 <= v < sh is known; only asked for when the load plan holds (steady rows) */) -> Raw {
         Raw r = {0u, 0u, 0u};
-        const uint8_t* row = src + wave_uniform64((long long)(inside ? v : reflect101(v, sh)) * src_stride);
+        const int rv = inside ? v : reflect101(v, sh);
         if (inside || plan) {
-            // (the lane's offset is made opaque per row: otherwise the compiler hoists base + offset out of the loop as a 64-bit
-            // pointer per lane -- two registers it then spills -- instead of the scalar-base + 32-bit-offset addressing form)
-            unsigned lane_off = goff;
-            asm volatile("" : "+v"(lane_off));
-            if (BGR) {   // one unaligned global_load_dwordx3, non-temporal: a frame's rows stream through once and should not evict
+            const int so = wave_uniform(rv * (int)src_stride);   // (< 2^31: a frame, or rows of the grey plane from the crop's origin on)
+            if (BGR) {   // one (unaligned) buffer_load_dwordx3, non-temporal: a frame's rows stream through once and should not evict
                          // the mask lines the other contexts' border followers are walking in (+2 % with four contexts)
-                typedef unsigned __attribute__((aligned(1))) uu;
-                const uu* p = reinterpret_cast<const uu*>(row + lane_off);
-                r.d0 = __builtin_nontemporal_load(p);
-                r.d1 = __builtin_nontemporal_load(p + 1);
-                r.d2 = __builtin_nontemporal_load(p + 2);
+                typedef unsigned v3u __attribute__((ext_vector_type(3)));
+                const v3u d = __builtin_amdgcn_raw_buffer_load_b96(src_rs, (int)goff, so, BUF_NT);
+                r.d0 = d.x; r.d1 = d.y; r.d2 = d.z;
             } else {     // crops: ordinary loads -- the two concentric quads of a marker give two crops over nearly the same pixels
-                __builtin_memcpy(&r, row + lane_off, 4);
+                r.d0 = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)goff, so, 0);
             }
             return r;
         }
+        const uint8_t* row = src + wave_uniform64((long long)rv * src_stride);
         if (!needed) return r;
         if (fast) {
             if (BGR) {
@@ -293,9 +338,17 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
 
     const int qa = Y0 / 2 - 3, qb = (Y1 + 3) / 2 + 1;
     const int v_first = 2 * qa - 2, v_last = 2 * qb + 2;
-    unsigned ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0;  // horizontal pyrDown sums of the last 5 rows (a | b<<16)
+    // Vertical pyrDown [1 4 6 4 1] by accumulation: pyramid row k (centre: source row 2k) is complete with source row 2k+2.  An
+    // even row 2k gives 1 to row k-1 (which it completes), 6 to row k, 1 to row k+1; an odd row gives 4 to its two neighbours.
+    // accA collects the row that completes next, accB the one after it (with the rounding constant): no 5-row window to shift.
+    us2 accA = as_us2(0u), accB = as_us2(0u);   // packed pairs (column c0 | column c0+2 << 16), <= 16 * 4080 + 128
     unsigned prevP = 0;                      // previous pyramid row for the bottom border
-    unsigned rAe = 0, rAo = 0, rBe = 0, rBo = 0;   // up-sampled pyramid rows q-2, q-1: even columns (r0|r2<<16), odd (r1|r3<<16)
+    // Vertical pyrUp, all values times four so that a finished pixel is the HIGH byte of its 16-bit sum (no shift; the ring insert
+    // picks that byte): with r(q) the horizontally up-sampled pyramid row q times 4 (even columns r0|r2<<16, odd r1|r3<<16),
+    // pyrUp row 2(q-1)   = (r(q-2) + 6 r(q-1) + r(q) + 128) >> 8,   pyrUp row 2(q-1)+1 = (4 (r(q-1) + r(q)) + 128) >> 8
+    // (the definition's (x + 32) >> 6 with x times 4; <= 4 * 16320 + 128 < 2^16).  Kept between rows: T = r(q-2) + 6 r(q-1) + 128
+    // and b = r(q-1) + 128 -- a new row costs one add for the even row, an add and a multiply-add for the odd row, two for the state.
+    us2 Te = as_us2(0u), To = as_us2(0u), be = as_us2(0u), bo = as_us2(0u);
     // The last 8 (virtual) pyrUp rows, one pair of registers per pixel with a row per byte, kept as a RING: virtual row vu goes
     // to byte vu & 3 of wa[p], which holds the current group of four rows (and, in the bytes not yet overwritten, the group
     // before the previous one); wb[p] holds the previous group; when a group begins the two words change names (v_swap_b32).
@@ -316,48 +369,53 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         constexpr bool S = decltype(steady_tag)::value;
         constexpr int PAR = decltype(parity_tag)::value;   // 1: v is odd, 2: v is even, 0: not known at compile time
         constexpr int VM = decltype(ring_tag)::value;      // v & 3 of an even steady row (the ring position follows from it), -1: not known
-        const Raw cur = nxt;
+        // Two rows in flight per wave (with one, the ~6 K resident waves have 4.7 MB under way, which at the latency of a loaded
+        // memory system caps the kernel near 4 TB/s): this row's words were loaded two rows ago, and the row after the next is
+        // requested as soon as they have been turned into grey -- into the registers they leave, so the two sets swap names
+        // every row and nothing is copied (loaded before, a third set was live and the sets rotated through moves).
+        unsigned g = to_grey(nxt);
+        if (BGR) asm volatile("" : "+v"(g) : : "memory");   // (keeps the load below this point, and the conversion above it)
+        else asm volatile("" : : : "memory");
         nxt = nxt2;
-        // issue the loads of the row after the next before this row's arithmetic: two rows in flight per wave -- with one, the
-        // ~6 K resident waves have 4.7 MB under way, which at the latency of a loaded memory system caps the kernel near 4 TB/s
         if (S || v + 1 < v_last) nxt2 = fetch(v + 2, S);
-        unsigned g = to_grey(cur);
-        if ((S || plan) && permuted) g = __builtin_amdgcn_perm(g, g, gsel);
-        if (BGR && o.gray && out_lane && (S || (v >= Y0 && v < Y1))) {  // rows [Y0,Y1) are real rows, each loaded exactly once
-            unsigned lane_off = out_off;
-            asm volatile("" : "+v"(lane_off));   // (see fetch)
-            uint8_t* q = o.gray + wave_uniform64((long long)v * o.gray_stride) + lane_off;
+        if (EDGE && (S || plan)) g = __builtin_amdgcn_perm(g, g, gsel);   // (gsel: the identity in lanes that hold no reflected columns)
+        if (BGR && (S || (v >= Y0 && v < Y1))) {  // (BGR: the frame pass, which always has a grey plane) rows [Y0,Y1) are real rows, each loaded exactly once
             // (steady rows: the plane's stride is a multiple of 4, so the width is, and every output lane holds 4 columns of it)
-            if (S || gray_dword) __builtin_nontemporal_store(g, reinterpret_cast<unsigned*>(q));
-            else
+            if (S || gray_dword) {
+                __builtin_amdgcn_raw_buffer_store_b32(g, gray_rs, (int)out_off, wave_uniform(v * (int)o.gray_stride), BUF_NT);
+            } else if (out_lane) {
+                uint8_t* q = o.gray + wave_uniform64((long long)v * o.gray_stride) + c0;
                 for (int j = 0; j < 4; j++)
                     if (c0 + j < sw) q[j] = (uint8_t)byte_of(g, j);
+            }
         }
+        us2 hsum;
         {   // horizontal [1 4 6 4 1] at the lane's two even columns c0 and c0+2
             const unsigned gl = up1(g), gr = down1(g);
             const unsigned a = dot4(alignb(g, gl, 2), 0x04060401u, byte_of(g, 2));
             const unsigned b = dot4(g, 0x04060401u, gr & 255u);
-            ph0 = ph1; ph1 = ph2; ph2 = ph3; ph3 = ph4;
-            ph4 = a | (b << 16);
+            hsum = as_us2(a | (b << 16));
         }
-        if (PAR == 1 || (PAR == 0 && ((v & 1) || (!S && v < v_first + 4)))) return;
+        if (PAR == 1 || (PAR == 0 && (v & 1))) {
+            accA += hsum * (unsigned short)4;
+            accB += hsum * (unsigned short)4;
+            return;
+        }
+        us2 P = (accA + hsum) >> (unsigned short)8;
+        accA = accB + hsum * (unsigned short)6;
+        accB = hsum + (unsigned short)128;
+        if (!S && v < v_first + 4) return;
         const int q = (v - 2) >> 1;  // pyramid row completed by source row 2q+2
-        us2 P = (as_us2(ph0) + as_us2(ph4) + (as_us2(ph1) + as_us2(ph3)) * (unsigned short)4 + as_us2(ph2) * (unsigned short)6 +
-                 (unsigned short)128) >> (unsigned short)8;
-        if (right_edge) {  // pyrUp right border: column pw stands for column pw-1
-            const unsigned left = up1(as_u32(P));
-            if (k0 + 1 == pw) P.y = P.x;
-            if (k0 == pw) P.x = (unsigned short)(left >> 16);
-        }
+        if (EDGE) P = as_us2(__builtin_amdgcn_perm(up1(as_u32(P)), as_u32(P), selP));   // pyrUp right border: column pw stands for column pw-1
         if (!S && q == ph_) P = as_us2(prevP);       // pyrUp bottom border: row ph stands for row ph-1
-        else if (S || q < ph_) prevP = as_u32(P);
+        else if (!S && q < ph_) prevP = as_u32(P);   // (steady rows end before source row sh-2: generic rows with q < ph follow them and set it)
         unsigned rCe, rCo;
         {   // horizontal up-sampling at the lane's 4 columns: even (r0,r2) and odd (r1,r3)
             const unsigned pk = as_u32(P);
             const us2 Lv = as_us2(alignb(pk, up1(pk), 2));     // (P[k0-1], P[k0])
             const us2 Rv = as_us2(alignb(down1(pk), pk, 2));   // (P[k0+1], P[k0+2])
-            rCe = as_u32(Lv + P * (unsigned short)6 + Rv);
-            rCo = as_u32((P + Rv) * (unsigned short)4);
+            rCe = as_u32((Lv + P * (unsigned short)6 + Rv) << (unsigned short)2);
+            rCo = as_u32((P + Rv) << (unsigned short)4);
         }
         if (S || q >= qa + 2) {
             for (int par = 0; par < 2; par++) {
@@ -365,29 +423,11 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                 if (!S && (u < 0 || u >= sh)) continue;
                 us2 Ue, Uo;   // pyrUp row u at the lane's even columns (c0, c0+2) and odd columns (c0+1, c0+3)
                 if (par == 0) {
-                    Ue = (as_us2(rAe) + as_us2(rBe) * (unsigned short)6 + as_us2(rCe) + (unsigned short)32) >> (unsigned short)6;
-                    Uo = (as_us2(rAo) + as_us2(rBo) * (unsigned short)6 + as_us2(rCo) + (unsigned short)32) >> (unsigned short)6;
-                } else {
-                    Ue = ((as_us2(rBe) + as_us2(rCe)) * (unsigned short)4 + (unsigned short)32) >> (unsigned short)6;
-                    Uo = ((as_us2(rBo) + as_us2(rCo)) * (unsigned short)4 + (unsigned short)32) >> (unsigned short)6;
-                }
-                // BORDER_REPLICATE of the Gaussian: columns < 0 take column 0, columns >= sw take column sw-1
-                // (packed pairs: Ue = (u0, u2), Uo = (u1, u3); the edge value is wave-uniform, the selects use constant lane masks)
-                if (left_edge) {
-                    const unsigned e2 = ((unsigned)__builtin_amdgcn_readlane((int)as_u32(Ue), HL) & 0xffffu) * 0x10001u;   // column 0
-                    Ue = as_us2(lane < HL ? e2 : as_u32(Ue));
-                    Uo = as_us2(lane < HL ? e2 : as_u32(Uo));
-                }
-                if (right_edge) {   // column sw-1 is pixel j1 (1 or 3: sw is even) of lane L1
-                    const unsigned o1 = (unsigned)__builtin_amdgcn_readlane((int)as_u32(Uo), L1 < 0 ? 0 : L1);
-                    const unsigned e = j1 == 1 ? (o1 & 0xffffu) : (o1 >> 16);
-                    const unsigned e2 = e * 0x10001u;
-                    Ue = as_us2(lane > L1 ? e2 : as_u32(Ue));
-                    Uo = as_us2(lane > L1 ? e2 : as_u32(Uo));
-                    if (j1 == 1) {   // pixels 2, 3 of lane L1 lie beyond the edge
-                        Ue = as_us2(lane == L1 ? ((as_u32(Ue) & 0xffffu) | (e << 16)) : as_u32(Ue));
-                        Uo = as_us2(lane == L1 ? ((as_u32(Uo) & 0xffffu) | (e << 16)) : as_u32(Uo));
-                    }
+                    Ue = Te + as_us2(rCe);
+                    Uo = To + as_us2(rCo);
+                } else {   // 4 (b - 128 + r) + 128 = 4 (b + r) - 384 (mod 2^16)
+                    Ue = (be + as_us2(rCe)) * (unsigned short)4 + (unsigned short)(65536 - 384);
+                    Uo = (bo + as_us2(rCo)) * (unsigned short)4 + (unsigned short)(65536 - 384);
                 }
                 // rows above 0 / below sh-1 replicate row 0 / sh-1; one more virtual row flushes the last mask row
                 const int vlo = (!S && u == 0) ? -3 : u, vhi = (!S && u == sh - 1) ? sh + 3 : u;
@@ -402,9 +442,9 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                             for (int p = 0; p < 4; p++) { const unsigned t = wa[p]; wa[p] = wb[p]; wb[p] = t; }
                         }
                     }
-                    {   // pixel p of the new row (u0, u2 = bytes 0, 2 of Ue; u1, u3 of Uo: each <= 255) into byte `slot` of wa[p]
+                    {   // pixel p of the new row (u0, u2 = bytes 1, 3 of Ue -- the high bytes of its halves --; u1, u3 of Uo) into byte `slot` of wa[p]
                         const unsigned kb = 8u * (unsigned)slot, keep = 0x03020100u & ~(0xffu << kb);
-                        const unsigned s4 = keep | (4u << kb), s6 = keep | (6u << kb);
+                        const unsigned s4 = keep | (5u << kb), s6 = keep | (7u << kb);
                         wa[0] = __builtin_amdgcn_perm(as_u32(Ue), wa[0], s4);
                         wa[1] = __builtin_amdgcn_perm(as_u32(Uo), wa[1], s4);
                         wa[2] = __builtin_amdgcn_perm(as_u32(Ue), wa[2], s6);
@@ -423,13 +463,21 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                         unsigned V[4];
 #pragma unroll
                         for (int p = 0; p < 4; p++) V[p] = dot4(wa[p], kwa, dot4(wb[p], kwb, 0u));
-                        const us2 Va = as_us2(V[0] | (V[1] << 16)), Vb = as_us2(V[2] | (V[3] << 16));
+                        const us2 Va = as_us2(V[0] | (V[1] << 16));
+                        us2 Vb = as_us2(V[2] | (V[3] << 16));
+                        if (EDGE) Vb = as_us2(__builtin_amdgcn_perm(as_u32(Va), as_u32(Vb), selB));   // (columns sw, sw+1 of the lane that straddles the right edge)
                         // horizontal pass: 16-bit column sums of this lane (Va = V0 V1, Vb = V2 V3), the lane to the left (l) and to
                         // the right (r), two taps per v_dot2_u32_u16 -- with neighbouring columns paired every pixel's 7 taps are 4
                         // instructions.  The accumulator starts at the rounding constant minus 8<<16:
                         // src - mean > -8  <=>  sum + 32768 - (8<<16) < src<<16
-                        const us2 Val = as_us2(up1(as_u32(Va))), Vbl = as_us2(up1(as_u32(Vb)));     // V-4 V-3, V-2 V-1
-                        const us2 Var = as_us2(down1(as_u32(Va))), Vbr = as_us2(down1(as_u32(Vb))); // V4 V5, V6 V7
+                        us2 Val = as_us2(up1(as_u32(Va))), Vbl = as_us2(up1(as_u32(Vb)));     // V-4 V-3, V-2 V-1
+                        us2 Var = as_us2(down1(as_u32(Va))), Vbr = as_us2(down1(as_u32(Vb))); // V4 V5, V6 V7
+                        if (EDGE) {   // BORDER_REPLICATE: columns < 0 are column 0, columns >= sw are column sw-1 (selL, selR above)
+                            Val = as_us2(__builtin_amdgcn_perm(as_u32(Va), as_u32(Val), selL));
+                            Vbl = as_us2(__builtin_amdgcn_perm(as_u32(Va), as_u32(Vbl), selL));
+                            Var = as_us2(__builtin_amdgcn_perm(as_u32(Vb), as_u32(Var), selR));
+                            Vbr = as_us2(__builtin_amdgcn_perm(as_u32(Vb), as_u32(Vbr), selR));
+                        }
                         const unsigned C0 = 32768u - (8u << 16);
                         const unsigned S0 = dot2(Val, K2(0, 8), dot2(Vbl, K2(28, 56), dot2(Va, K2(72, 56), dot2(Vb, K2(28, 8), C0))));
                         const unsigned S1 = dot2(Vbl, K2(8, 28), dot2(Va, K2(56, 72), dot2(Vb, K2(56, 28), dot2(Var, K2(8, 0), C0))));
@@ -441,13 +489,13 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                         if constexpr (VM >= 0) {
                             constexpr int TS = ((VM & 3) + 5) & 7;   // par = 0; par = 1 is the next slot
                             if (par == 0) {
-                                push_bit<TS & 3>(nib, S3, TS < 4 ? wa[3] : wb[3]);
+                                first_bit<TS & 3>(nib, S3, TS < 4 ? wa[3] : wb[3]);
                                 push_bit<TS & 3>(nib, S2, TS < 4 ? wa[2] : wb[2]);
                                 push_bit<TS & 3>(nib, S1, TS < 4 ? wa[1] : wb[1]);
                                 push_bit<TS & 3>(nib, S0, TS < 4 ? wa[0] : wb[0]);
                             } else {
                                 constexpr int T1 = (TS + 1) & 7;
-                                push_bit<T1 & 3>(nib, S3, T1 < 4 ? wa[3] : wb[3]);
+                                first_bit<T1 & 3>(nib, S3, T1 < 4 ? wa[3] : wb[3]);
                                 push_bit<T1 & 3>(nib, S2, T1 < 4 ? wa[2] : wb[2]);
                                 push_bit<T1 & 3>(nib, S1, T1 < 4 ? wa[1] : wb[1]);
                                 push_bit<T1 & 3>(nib, S0, T1 < 4 ? wa[0] : wb[0]);
@@ -461,17 +509,23 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                             OCVAR_PUSH_BIT(S0, 0);
 #undef OCVAR_PUSH_BIT
                         }
-                        nib &= colmask;
+                        if (EDGE || VM < 0) nib &= colmask;   // (strips inside the image: every column counts, and the four tests above left four bits)
                     }
                     // Row y's window -> table: its share of the masks of rows y-1, y, y+1 and its start nibbles.
-                    const unsigned wdw = (nib << 1) | (up1(nib) >> 3) | ((down1(nib) & rmask) << 5);
-                    const uint4 T = tab[wdw];
+                    // Byte offset of the table entry (16 bytes each; the table is laid out for it): bits 4..7 = own pixels, bit 8 = the left
+                    // lane's pixel 3, bits 9, 10 = the right lane's pixels 0, 1 -- every lane shifts its nibble once, the neighbours'
+                    // parts are an AND on the DPP-shifted value and a shift-or each.
+                    const unsigned n4 = nib << 4;
+                    const unsigned wdw16 = ((down1(n4) & rmask4) << 5) | (((up1(n4) & bit7) << 1) | n4);
+                    const uint4 T = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(tab) + wdw16);
                     const unsigned nbr4 = m_prev | T.z;        // row y-1: E | NE N NW | W | SW S SE complete
-                    unsigned st = T.w & (x_prev >> 16);        // row y's own nibbles & row y-1's "row above" nibbles
+                    unsigned st;                               // row y's own nibbles (low half of T.w) & row y-1's "row above" nibbles (high half of x_prev)
+                    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(st) : "v"(T.w), "v"(x_prev));
                     m_prev = u_prev | T.y;
                     u_prev = T.x;
                     x_prev = T.w;
-                    st = st & ~(st >> 4) & pxsel;              // bits 0..3: outer starts, bits 8..11: hole starts of row y
+                    st = st & ~(st >> 4);                      // bits 0..3: outer starts, bits 8..11: hole starts of row y (other bits: don't care)
+                    if (EDGE) st &= pxsel;
                     const int yr = y - 1;
                     if (S || (yr >= Y0 && yr < Y1)) {
                         rowbuf[(yr & 7) * 64 + lane] = nbr4;
@@ -482,22 +536,24 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
                     // above E's east neighbour foreground: that one belongs to the same 8-connected component and comes earlier).
                     // Hole: background pixel whose W and N are foreground -- and E or NE foreground (if both are background they
                     // belong to the same 4-connected background region and NE comes earlier).
-                    if ((!S && (y < Y0 || y >= Y1)) || __ballot(st != 0) == 0) continue;
+                    if ((!S && (y < Y0 || y >= Y1)) || (__ballot((st & 0xf0fu) != 0) & (EDGE ? ~0ull : OUT_LANES)) == 0) continue;
 #pragma nounroll   // (rare rows, and the steady loop holds eight copies of this: kept small)
                     for (int j = 0; j < 4; j++) {
                         const int type = ((st >> j) & 1u) ? 0 : ((st >> (8 + j)) & 1u) ? 1 : -1;
-                        const unsigned long long mask = __ballot(type >= 0);
+                        const unsigned long long mask = __ballot(type >= 0) & (EDGE ? ~0ull : OUT_LANES);
                         if (!mask) continue;
                         const int n = __popcll(mask);
                         if (staged + n > MARCH_STAGE) flush();
-                        if (type >= 0) stage[staged + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)(y * o.ns + c0 + j) | ((unsigned)type << 31);
+                        if ((mask >> lane) & 1ull) stage[staged + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)(y * o.ns + c0 + j) | ((unsigned)type << 31);
                         staged += n;
                     }
                 }
             }
         }
-        rAe = rBe; rAo = rBo;
-        rBe = rCe; rBo = rCo;
+        Te = as_us2(rCe) * (unsigned short)6 + be;
+        To = as_us2(rCo) * (unsigned short)6 + bo;
+        be = as_us2(rCe) + (unsigned short)128;
+        bo = as_us2(rCo) + (unsigned short)128;
     };
     // steady rows: v and v+1 are real rows of this unit ([Y0, Y1), v+1 <= sh-1), and the rows an even v completes -- pyrUp
     // rows v-4, v-3, threshold rows v-7, v-6, mask rows v-8, v-7 -- are inside the unit, at least one row away from the
@@ -533,11 +589,11 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     flush();
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void binarise_frames_kernel(Workspace ws, const uint8_t* bgr, int row_stride, size_t frame_stride) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCVAR_WAVES_F, 8))) void binarise_frames_kernel(Workspace ws, const uint8_t* bgr, int row_stride, size_t frame_stride) {
     __shared__ unsigned stage[4][MARCH_STAGE];
     __shared__ __attribute__((aligned(16))) unsigned rowbuf[4][8 * 64];
     __shared__ uint4 tab[128];
-    if (threadIdx.x < 128) tab[threadIdx.x] = mask_table_entry(threadIdx.x);
+    if (threadIdx.x < 128) tab[threadIdx.x] = mask_table_entry(table_window(threadIdx.x));
     __syncthreads();
     const int per_frame = ws.frame_strips * ws.frame_chunks;
     // XCD-aware order.  Consecutive workgroups go round the 8 XCDs, each with its own L2; in launch order the workgroups of one
@@ -604,11 +660,11 @@ __global__ __launch_bounds__(256) void grey_writeback_kernel(Workspace ws, uint8
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void binarise_crops_kernel(Workspace ws) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCVAR_WAVES_C, 8))) void binarise_crops_kernel(Workspace ws) {
     __shared__ unsigned stage[4][MARCH_STAGE];
     __shared__ __attribute__((aligned(16))) unsigned rowbuf[4][8 * 64];
     __shared__ uint4 tab[128];
-    if (threadIdx.x < 128) tab[threadIdx.x] = mask_table_entry(threadIdx.x);
+    if (threadIdx.x < 128) tab[threadIdx.x] = mask_table_entry(table_window(threadIdx.x));
     __syncthreads();
     int n_units = ws.counters[CNT_CROP_TILES];
     if (n_units > ws.cap_crop_tiles) n_units = ws.cap_crop_tiles;
