@@ -282,10 +282,11 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         const int rv = inside ? v : reflect101(v, sh);
         if (inside || plan) {
             const int so = wave_uniform(rv * (int)src_stride);   // (< 2^31: a frame, or rows of the grey plane from the crop's origin on)
-            if (BGR) {   // one (unaligned) buffer_load_dwordx3, non-temporal: a frame's rows stream through once and should not evict
-                         // the mask lines the other contexts' border followers are walking in (+2 % with four contexts)
+            if (BGR) {   // one (unaligned) buffer_load_dwordx3.  Not non-temporal: with the hint the kernel is 7 % slower alone on the GPU
+                         // (5.8 against 5.4 ms per 2048 frames: the halo columns two strips share stop hitting in the L2); the grey
+                         // and mask STORES carry it (+2 % with four contexts, round 3)
                 typedef unsigned v3u __attribute__((ext_vector_type(3)));
-                const v3u d = __builtin_amdgcn_raw_buffer_load_b96(src_rs, (int)goff, so, BUF_NT);
+                const v3u d = __builtin_amdgcn_raw_buffer_load_b96(src_rs, (int)goff, so, 0);
                 r.d0 = d.x; r.d1 = d.y; r.d2 = d.z;
             } else {     // crops: ordinary loads -- the two concentric quads of a marker give two crops over nearly the same pixels
                 r.d0 = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)goff, so, 0);
