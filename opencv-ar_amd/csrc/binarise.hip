@@ -25,6 +25,9 @@
 #ifndef OCVAR_WAVES_F
 #define OCVAR_WAVES_F 5   // waves per SIMD the frame kernel is compiled for (register budget 512 / n, in eights)
 #endif
+#ifndef OCVAR_ROWS_AHEAD_F
+#define OCVAR_ROWS_AHEAD_F 2   // source rows a wave of the frame kernel has under way beyond the one it works on (1 .. 3)
+#endif
 #ifndef OCVAR_WAVES_C
 #define OCVAR_WAVES_C 5   // ... and the crop kernel
 #endif
@@ -365,7 +368,14 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     // One source row.  S ("steady"): v lies where every range test below has a known outcome -- the rows it completes are
     // inside the work unit and away from the image's first and last rows -- so the tests (a scalar compare and branch
     // each, dozens per row) are compiled out; the rows at the top and bottom of a unit take the generic instance.
-    Raw nxt = fetch(v_first, false), nxt2 = fetch(v_first + 1, false);
+    // Source rows in flight per wave: AHEAD rows beyond the one being worked on (frames: 2, crops: 1).  With one row under way the
+    // ~6 K resident waves have 4.7 MB in flight, which at the latency of a loaded memory system caps the frame kernel near 4 TB/s;
+    // and when other contexts' kernels hold half of the wave slots the frame kernel's waves must each keep more in flight to
+    // keep the memory system busy.
+    constexpr int AHEAD = BGR ? OCVAR_ROWS_AHEAD_F : 1;
+    Raw nxt = fetch(v_first, false), nxt2 = fetch(v_first + 1, false), nxt3 = {0u, 0u, 0u}, nxt4 = {0u, 0u, 0u};
+    if (AHEAD >= 2) nxt3 = fetch(v_first + 2, false);
+    if (AHEAD >= 3) nxt4 = fetch(v_first + 3, false);
     auto row = [&](const int v, auto steady_tag, auto parity_tag, auto ring_tag) {
         constexpr bool S = decltype(steady_tag)::value;
         constexpr int PAR = decltype(parity_tag)::value;   // 1: v is odd, 2: v is even, 0: not known at compile time
@@ -377,8 +387,17 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         unsigned g = to_grey(nxt);
         if (BGR) asm volatile("" : "+v"(g) : : "memory");   // (keeps the load below this point, and the conversion above it)
         else asm volatile("" : : : "memory");
-        nxt = nxt2;
-        if (S || v + 1 < v_last) nxt2 = fetch(v + 2, S);
+        // (the request goes into the registers the converted row leaves: the sets swap names, nothing is copied in the unrolled loop)
+        if (AHEAD == 1) {
+            nxt = nxt2;
+            if (S || v + 1 < v_last) nxt2 = fetch(v + 2, S);
+        } else if (AHEAD == 2) {
+            nxt = nxt2; nxt2 = nxt3;
+            if (S || v + 2 < v_last) nxt3 = fetch(v + 3, S);
+        } else {
+            nxt = nxt2; nxt2 = nxt3; nxt3 = nxt4;
+            if (S || v + 3 < v_last) nxt4 = fetch(v + 4, S);
+        }
         if (EDGE && (S || plan)) g = __builtin_amdgcn_perm(g, g, gsel);   // (gsel: the identity in lanes that hold no reflected columns)
         if (BGR && (S || (v >= Y0 && v < Y1))) {  // (BGR: the frame pass, which always has a grey plane) rows [Y0,Y1) are real rows, each loaded exactly once
             // (steady rows: the plane's stride is a multiple of 4, so the width is, and every output lane holds 4 columns of it)
@@ -562,7 +581,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     // -- and the unit has the load plan and whole-dword grey stores (else no row is steady: the steady instance of the row body
     // carries neither the byte-wise loads of images narrower than 32 columns nor byte-wise grey stores)
     const bool steady_ok = plan && (!(BGR && o.gray) || (o.gray_stride & 3) == 0);
-    const int vs0 = (Y0 + 8 > 8 ? Y0 + 8 : 8) | 1, vs1 = !steady_ok ? -1 : Y1 - 1 < sh - 3 ? Y1 - 1 : sh - 3;   // (vs0 odd: steady rows run in pairs; v + 2 is a real row: prefetched unreflected)
+    const int vs0 = (Y0 + 8 > 8 ? Y0 + 8 : 8) | 1, vs1 = !steady_ok ? -1 : Y1 - 1 < sh - 2 - AHEAD ? Y1 - 1 : sh - 2 - AHEAD;   // (vs0 odd: steady rows run in pairs; v + 2 is a real row: prefetched unreflected)
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     using P2 = std::integral_constant<int, 2>;
