@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8192, help="frames per GPU per step (over all streams)")
-    ap.add_argument("--streams", type=int, default=4, help="independent detector contexts / HIP streams per GPU; the batch is split over them")
+    ap.add_argument("--streams", type=int, default=5, help="independent detector contexts / HIP streams per GPU; the batch is split over them")
     ap.add_argument("--gate", type=int, default=2, help="at most this many binarise kernels of the contexts run at once (ocvar_hip_gate_create; 0: no gate)")
     ap.add_argument("--unique", type=int, default=256, help="distinct synthetic frames per GPU (tiled to the batch on the device)")
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config id (3 = headline)")

@@ -28,6 +28,9 @@
 #ifndef OCVAR_ROWS_AHEAD_F
 #define OCVAR_ROWS_AHEAD_F 2   // source rows a wave of the frame kernel has under way beyond the one it works on (1 .. 3)
 #endif
+#ifndef OCVAR_BIN_WG_WAVES
+#define OCVAR_BIN_WG_WAVES 1   // waves per workgroup of the two binarise kernels (1: a wave can take any SIMD with room for it)
+#endif
 #ifndef OCVAR_WAVES_C
 #define OCVAR_WAVES_C 5   // ... and the crop kernel
 #endif
@@ -609,11 +612,16 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     flush();
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCVAR_WAVES_F, 8))) void binarise_frames_kernel(Workspace ws, const uint8_t* bgr, int row_stride, size_t frame_stride) {
-    __shared__ unsigned stage[4][MARCH_STAGE];
-    __shared__ __attribute__((aligned(16))) unsigned rowbuf[4][8 * 64];
+// Workgroups of ONE wave (BW = 1): the waves of a workgroup must be placed on their CU together, so a four-wave workgroup needs
+// room on all four SIMDs at once -- and with other contexts' kernels on the GPU (a follower wave of 110 registers on one SIMD)
+// a CU holds a whole workgroup less.  A one-wave workgroup takes any SIMD with 96 free registers and 6 KB of LDS.
+constexpr int BW = OCVAR_BIN_WG_WAVES;
+
+__global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(OCVAR_WAVES_F, 8))) void binarise_frames_kernel(Workspace ws, const uint8_t* bgr, int row_stride, size_t frame_stride) {
+    __shared__ unsigned stage[BW][MARCH_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned rowbuf[BW][8 * 64];
     __shared__ uint4 tab[128];
-    if (threadIdx.x < 128) tab[threadIdx.x] = mask_table_entry(table_window(threadIdx.x));
+    for (unsigned i = threadIdx.x; i < 128u; i += 64u * BW) tab[i] = mask_table_entry(table_window(i));
     __syncthreads();
     const int per_frame = ws.frame_strips * ws.frame_chunks;
     // XCD-aware order.  Consecutive workgroups go round the 8 XCDs, each with its own L2; in launch order the workgroups of one
@@ -622,14 +630,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCVAR_WAVES
     // workgroup (b / 8) % G of that frame (G workgroups per frame): a frame's workgroups run on one XCD, next to each other in
     // time.  (Only when a frame is a whole number of workgroups; the frames beyond the last group of 8 keep launch order.)
     int wg = (int)blockIdx.x;
-    if ((per_frame & 3) == 0) {
-        const int G = per_frame >> 2, grouped = (ws.n_frames & ~7) * G;
+    if (per_frame % BW == 0) {
+        const int G = per_frame / BW, grouped = (ws.n_frames & ~7) * G;
         if (wg < grouped) {
             const int k = wg >> 3;
             wg = ((k / G) * 8 + (wg & 7)) * G + k % G;
         }
     }
-    const int unit = wg * 4 + wave_uniform((int)(threadIdx.x >> 6));
+    const int unit = wg * BW + wave_uniform((int)(threadIdx.x >> 6));
     if (unit >= per_frame * ws.n_frames) return;
     const int f = unit / per_frame, rem = unit % per_frame;
     const int chunk = rem / ws.frame_strips, strip = rem % ws.frame_strips;
@@ -680,11 +688,11 @@ __global__ __launch_bounds__(256) void grey_writeback_kernel(Workspace ws, uint8
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCVAR_WAVES_C, 8))) void binarise_crops_kernel(Workspace ws) {
-    __shared__ unsigned stage[4][MARCH_STAGE];
-    __shared__ __attribute__((aligned(16))) unsigned rowbuf[4][8 * 64];
+__global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(OCVAR_WAVES_C, 8))) void binarise_crops_kernel(Workspace ws) {
+    __shared__ unsigned stage[BW][MARCH_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned rowbuf[BW][8 * 64];
     __shared__ uint4 tab[128];
-    if (threadIdx.x < 128) tab[threadIdx.x] = mask_table_entry(table_window(threadIdx.x));
+    for (unsigned i = threadIdx.x; i < 128u; i += 64u * BW) tab[i] = mask_table_entry(table_window(i));
     __syncthreads();
     int n_units = ws.counters[CNT_CROP_TILES];
     if (n_units > ws.cap_crop_tiles) n_units = ws.cap_crop_tiles;
@@ -727,7 +735,7 @@ void launch_binarise_frames(const Workspace& ws, const uint8_t* d_bgr, int row_s
                             hipStream_t stream) {
     const int units = ws.frame_strips * ws.frame_chunks * ws.n_frames;
     if (units <= 0) return;
-    hipLaunchKernelGGL(binarise_frames_kernel, dim3((units + 3) / 4), dim3(256), 0, stream, ws, d_bgr, row_stride, frame_stride);
+    hipLaunchKernelGGL(binarise_frames_kernel, dim3((units + BW - 1) / BW), dim3(64 * BW), 0, stream, ws, d_bgr, row_stride, frame_stride);
     if (ws.W > ws.sw || ws.H > ws.sh)
         hipLaunchKernelGGL(grey_edges_kernel, dim3(8, ws.n_frames), dim3(256), 0, stream, ws, d_bgr, row_stride, frame_stride);
     if (grey_in_place)
@@ -736,7 +744,7 @@ void launch_binarise_frames(const Workspace& ws, const uint8_t* d_bgr, int row_s
 }
 
 void launch_binarise_crops(const Workspace& ws, hipStream_t stream) {
-    hipLaunchKernelGGL(binarise_crops_kernel, dim3(ws.crop_blocks), dim3(256), 0, stream, ws);
+    hipLaunchKernelGGL(binarise_crops_kernel, dim3(ws.crop_blocks * (4 / BW)), dim3(64 * BW), 0, stream, ws);   // (crop_blocks counts four waves each)
 }
 
 }  // namespace ocvar
