@@ -31,6 +31,9 @@
 #ifndef OCVAR_BIN_WG_WAVES
 #define OCVAR_BIN_WG_WAVES 1   // waves per workgroup of the two binarise kernels (1: a wave can take any SIMD with room for it)
 #endif
+#ifndef OCVAR_ROWS_AHEAD_C
+#define OCVAR_ROWS_AHEAD_C 1   // ... of the crop kernel
+#endif
 #ifndef OCVAR_WAVES_C
 #define OCVAR_WAVES_C 5   // ... and the crop kernel
 #endif
@@ -375,7 +378,7 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     // ~6 K resident waves have 4.7 MB in flight, which at the latency of a loaded memory system caps the frame kernel near 4 TB/s;
     // and when other contexts' kernels hold half of the wave slots the frame kernel's waves must each keep more in flight to
     // keep the memory system busy.
-    constexpr int AHEAD = BGR ? OCVAR_ROWS_AHEAD_F : 1;
+    constexpr int AHEAD = BGR ? OCVAR_ROWS_AHEAD_F : OCVAR_ROWS_AHEAD_C;
     Raw nxt = fetch(v_first, false), nxt2 = fetch(v_first + 1, false), nxt3 = {0u, 0u, 0u}, nxt4 = {0u, 0u, 0u};
     if (AHEAD >= 2) nxt3 = fetch(v_first + 2, false);
     if (AHEAD >= 3) nxt4 = fetch(v_first + 3, false);

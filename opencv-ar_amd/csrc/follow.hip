@@ -1351,7 +1351,7 @@ void launch_follow_long_crops(const Workspace& ws, hipStream_t stream) {
     hipLaunchKernelGGL(follow_long_kernel<true>, dim3(ws.long_blocks * (4 / FW)), dim3(FOLLOW_THREADS), 0, stream, ws);
 }
 void launch_order_and_crops(const Workspace& ws, hipStream_t stream) {
-    if (ws.n_frames > 0) hipLaunchKernelGGL(order_and_crops_kernel, dim3(ws.n_frames), dim3(256), (size_t)ws.maxq * 9 * sizeof(int), stream, ws);
+    if (ws.n_frames > 0) hipLaunchKernelGGL(order_and_crops_kernel, dim3(ws.n_frames), dim3(ws.maxq <= 256 ? 64 : 256) /* one wave: starts wherever a SIMD has room */, (size_t)ws.maxq * 9 * sizeof(int), stream, ws);
 }
 
 }  // namespace ocvar
