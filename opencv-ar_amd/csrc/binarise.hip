@@ -241,20 +241,25 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     // (vmcnt counts loads and stores in order).  Y0 is a multiple of 8 (api.hip / MARCH_CROP_ROWS), so a group of 8 rows
     // belongs to one work unit; padding rows/columns of the plane (rows up to sh rounded to 8, columns up to ns) may
     // receive stale values, nothing reads them.
-    const int tile_x = strip * (SV / 16) + (lane >> 2);          // lanes 0..59: tile of this strip, 4 lanes per tile
-    const bool flush_lane = lane < 4 * (SV / 16) && tile_x * 16 < o.ns;
-    const unsigned flush_src = (unsigned)(2 * (lane & 3)) * 64u + (unsigned)(HL + 4 * (lane >> 2));   // dword index in rowbuf: row 2p, first lane of the tile
-    const unsigned flush_dst = flush_lane ? ((unsigned)tile_x << 7) + (unsigned)(2 * (lane & 3)) * 16u : OOB;   // byte offset inside a tile row group
+    // A group of 8 rows is 15 tiles of 128 bytes = 120 pieces of 16 bytes (piece k: row k & 7 of tile k >> 3, at byte 16 k of the
+    // strip's part of the tile row group).  Two store instructions, each writing CONTIGUOUS memory: lane l stores piece l, then
+    // (l < 56) piece 64 + l -- every 64-byte sector is written whole by one instruction.  (Lane = (pair of rows, tile) with both
+    // rows' pieces from one lane made every instruction write 16-byte pieces at a stride of 32: twice the write requests, each
+    // half a sector.)  Piece 64 + l is the same row, eight tiles (32 lanes' dwords) further on: one LDS offset register.
+    const int tile1 = strip * (SV / 16) + (lane >> 3), tile2 = tile1 + 8;
+    const unsigned flush_src = (unsigned)(lane & 7) * 64u + (unsigned)(HL + 4 * (lane >> 3));   // dword index in rowbuf: row l & 7, first lane of tile l >> 3
+    const unsigned flush_dst1 = tile1 * 16 < o.ns ? ((unsigned)tile1 << 7) + (unsigned)(lane & 7) * 16u : OOB;   // byte offsets inside a tile row group
+    const unsigned flush_dst2 = lane < 56 && tile2 * 16 < o.ns ? ((unsigned)tile2 << 7) + (unsigned)(lane & 7) * 16u : OOB;
     auto flush_rows = [&](int yr_last) {   // yr_last: last row written; its group is complete or the unit ends
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         {
-            const uint2* s0 = reinterpret_cast<const uint2*>(rowbuf + flush_src);   // (lanes 60..63 read past the tiles, at most two dwords past this wave's rows: their store is dropped)
-            const uint2 a0 = s0[0], a1 = s0[1];       // row 2p: 16 bytes
-            const uint2 b0 = s0[32], b1 = s0[33];     // row 2p+1 (one row = 64 dwords = 32 uint2)
+            const uint2* s0 = reinterpret_cast<const uint2*>(rowbuf + flush_src);   // (lanes 56..63 read past the tiles in the second read, inside this wave's rows: their store is dropped)
+            const uint2 a0 = s0[0], a1 = s0[1];       // piece l: 16 bytes
+            const uint2 b0 = s0[16], b1 = s0[17];     // piece 64 + l: 32 dwords further on
             const int so = wave_uniform(((yr_last >> 3) * (o.ns >> 4)) << 7);
             typedef unsigned v4u __attribute__((ext_vector_type(4)));   // (non-temporal stores: written once, read much later)
-            __builtin_amdgcn_raw_buffer_store_b128((v4u){a0.x, a0.y, a1.x, a1.y}, nbr_rs, (int)flush_dst, so, BUF_NT);
-            __builtin_amdgcn_raw_buffer_store_b128((v4u){b0.x, b0.y, b1.x, b1.y}, nbr_rs, (int)flush_dst, so + 16, BUF_NT);   // (+16 on the scalar side: no second offset register)
+            __builtin_amdgcn_raw_buffer_store_b128((v4u){a0.x, a0.y, a1.x, a1.y}, nbr_rs, (int)flush_dst1, so, BUF_NT);
+            __builtin_amdgcn_raw_buffer_store_b128((v4u){b0.x, b0.y, b1.x, b1.y}, nbr_rs, (int)flush_dst2, so, BUF_NT);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     };

@@ -12,6 +12,9 @@ tpls = oa.load_templates([os.path.join(oa.TEMPLATE_DIR, n + ".png") for n in H.T
 cam = oa.default_camera(cfg.width, cfg.height)
 det = oa.Detector(cfg.width, cfg.height, max_batch=B)
 det.set_templates(tpls); det.set_camera(cam)
+gate = oa.Gate(2, 0) if os.environ.get("TRAFFIC_GATE", "1") == "1" else None   # a context with a gate takes the launch geometry bench.py's contexts take
+if gate is not None:
+    det.set_gate(gate)
 assert oa.hip_lib().ocvar_hip_debug_calibrate(det._ctx, CAL) == 0
 d = torch.from_numpy(base).cuda().repeat((B + len(base) - 1) // len(base), 1, 1, 1)[:B].contiguous()   # tiled on the device
 torch.cuda.synchronize()
