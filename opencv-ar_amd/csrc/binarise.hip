@@ -351,7 +351,11 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
         return g01 | (g23 << 16);
     };
 
-    const int qa = Y0 / 2 - 3, qb = (Y1 + 3) / 2 + 1;
+    // Pyramid rows the unit needs: from qa (two rows before the first pyrUp row, Y0 - 4, that its first threshold row reads) to qb.
+    // At the image's top the rows above 0 are copies of row 0 (BORDER_REPLICATE), so nothing before pyramid row -1 is read; at its
+    // bottom the last pyrUp rows, sh - 2 and sh - 1, come with pyramid row sh / 2 (= row sh / 2 - 1 again) and the rows below are
+    // copies: four source rows less at either end than the general formula asks for (a crop of 170 rows: 8 of 187).
+    const int qa = Y0 == 0 ? -1 : Y0 / 2 - 3, qb = (Y1 + 3) / 2 + 1 < sh / 2 ? (Y1 + 3) / 2 + 1 : sh / 2;
     const int v_first = 2 * qa - 2, v_last = 2 * qb + 2;
     // Vertical pyrDown [1 4 6 4 1] by accumulation: pyramid row k (centre: source row 2k) is complete with source row 2k+2.  An
     // even row 2k gives 1 to row k-1 (which it completes), 6 to row k, 1 to row k+1; an odd row gives 4 to its two neighbours.
