@@ -206,3 +206,19 @@ def oracle_contours(bin_img):
                                    P(holes), maxc)
     assert n >= 0
     return [pts[2 * offs[i]:2 * offs[i + 1]].reshape(-1, 2).copy() for i in range(n)], starts[:n].copy(), holes[:n].copy()
+
+
+def neighbour_masks(binary):
+    """8-neighbour masks of a binary image as the frame pass stores them (bit s: the neighbour in direction s = E,NE,N,NW,W,SW,S,SE
+    is set), with the 1-pixel frame zeroed first as cvFindContours does."""
+    bz = (np.asarray(binary) > 0).astype(np.uint8)
+    bz[0, :] = bz[-1, :] = 0
+    bz[:, 0] = bz[:, -1] = 0
+    pad = np.pad(bz, 1)
+    h, w = bz.shape
+    dx = [1, 1, 0, -1, -1, -1, 0, 1]
+    dy = [0, -1, -1, -1, 0, 1, 1, 1]
+    out = np.zeros_like(bz)
+    for k in range(8):
+        out |= pad[1 + dy[k]:1 + dy[k] + h, 1 + dx[k]:1 + dx[k] + w] << k
+    return out

@@ -40,6 +40,8 @@ def check_frame(det, f, frame_bgr, tpls, cam, markers, counts, prev=None):
     b_ref = H.oracle_binarise(np.ascontiguousarray(grey[..., 0]))
     b_gpu = det.debug_binary(f, w, h)
     assert np.array_equal(b_gpu[1:-1, 1:-1], b_ref[1:-1, 1:-1])
+    # every bit of the neighbour-mask plane the border followers walk on
+    assert np.array_equal(det.debug_masks(f, w, h), H.neighbour_masks(b_ref))
     if prev is None:
         q_ref = H.oracle_find_squares(np.ascontiguousarray(grey[..., 0]))
         q_gpu = det.debug_frame_quads(f)
