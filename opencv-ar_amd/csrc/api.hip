@@ -121,7 +121,7 @@ extern "C" int ocvar_hip_create_ex(OcvarHip** out, int device, int max_width, in
     w.cap_pool_ints = (long long)B * (1 << 18) + (1 << 24);
     w.cap_crop_pixels = (long long)(2 * B * (size_t)(max_width + 16) * (max_height + 8));
     int rc;
-    if ((rc = dev_alloc(c, &w.gray, B * WH))) return rc;
+    if ((rc = dev_alloc(c, &w.gray, B * (size_t)gray_plane_bytes(max_width, max_height)))) return rc;   // (panels: hd.h::gray_col)
     if ((rc = dev_alloc(c, &w.nbr_frame, B * (size_t)(max_width + 16) * (max_height + 8)))) return rc;
     if ((rc = dev_alloc(c, &w.nbr_crop, (size_t)w.cap_crop_pixels))) return rc;
     if ((rc = dev_alloc(c, &w.cands_frame, (size_t)w.cap_frame_cands))) return rc;
@@ -837,8 +837,12 @@ extern "C" int ocvar_hip_find_squares(OcvarHip* c, const uint8_t* h_gray, int wi
 extern "C" int ocvar_hip_debug_gray(OcvarHip* c, int frame, uint8_t* h) {
     if (!c || !h || frame < 0 || frame >= c->ws.n_frames) return OCVAR_E_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t wh = (size_t)c->ws.W * c->ws.H;
-    HIP_TRY(c, hipMemcpy(h, c->ws.gray + frame * wh, wh, hipMemcpyDeviceToHost));
+    const int W = c->ws.W, H = c->ws.H, pitch = gray_pitch(W);
+    const size_t plane = (size_t)gray_plane_bytes(W, H);
+    std::vector<uint8_t> g(plane);
+    HIP_TRY(c, hipMemcpy(g.data(), c->ws.gray + frame * plane, plane, hipMemcpyDeviceToHost));
+    for (int y = 0; y < H; y++)   // out of the panels, into plain rows
+        for (int x = 0; x < W; x++) h[(size_t)y * W + x] = g[(size_t)y * pitch + gray_col(x)];
     return OCVAR_OK;
 }
 

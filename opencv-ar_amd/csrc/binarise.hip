@@ -159,7 +159,7 @@ struct MarchOut {
 // EDGE = false: the strip lies strictly inside the image (no lane holds a column < 0 or >= sw), so the border rules of the
 // filters and their lane masks are compiled out -- six of a 1080p frame's eight strips; a crop's strips always touch an edge.
 template <bool BGR, bool EDGE>
-__device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int sh, int strip, int Y0, int Y1, const MarchOut& o,
+__device__ void march_unit(const uint8_t* src, long long src_stride, int x_org /* crops: the ROI's first column in the frame's grey plane */, int sw, int sh, int strip, int Y0, int Y1, const MarchOut& o,
                            unsigned* stage, unsigned* rowbuf /* LDS, 8 rows x 64 lanes */, const uint4* tab /* LDS, mask_table_entry */) {
     const int lane = threadIdx.x & 63;
     const int XS = strip * SV - 4 * HL;
@@ -186,14 +186,16 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     const unsigned selL = EDGE && c0 == 0 ? 0x05040504u : SEL_ID;
     const unsigned selB = EDGE && c0 + 2 == sw ? 0x07060706u : SEL_ID;
     const unsigned selR = EDGE && c0 < sw && c0 + 4 >= sw ? 0x07060706u : SEL_ID;
-    const bool gray_dword = o.gray && (o.gray_stride & 3) == 0 && (!EDGE || c0 + 3 < sw);
+    // byte offset of source column c (0 <= c < sw) in its row: 3 c in a BGR frame; in the panelled grey plane (hd.h::gray_col) the
+    // crop's column c is the frame's column x_org + c (up to 9 consecutive columns follow contiguously from any column)
+    auto col_off = [&](int c) -> unsigned { return BGR ? (unsigned)(3 * c) : gray_col(x_org + c); };
     // reflected source columns of the lanes that straddle an image edge (BORDER_REFLECT_101)
-    int xr0 = 0, xr1 = 0, xr2 = 0, xr3 = 0;
+    unsigned xr0 = 0, xr1 = 0, xr2 = 0, xr3 = 0;
     if (needed && !fast) {
-        xr0 = reflect101(c0, sw) * (BGR ? 3 : 1);
-        xr1 = reflect101(c0 + 1, sw) * (BGR ? 3 : 1);
-        xr2 = reflect101(c0 + 2, sw) * (BGR ? 3 : 1);
-        xr3 = reflect101(c0 + 3, sw) * (BGR ? 3 : 1);
+        xr0 = col_off(reflect101(c0, sw));
+        xr1 = col_off(reflect101(c0 + 1, sw));
+        xr2 = col_off(reflect101(c0 + 2, sw));
+        xr3 = col_off(reflect101(c0 + 3, sw));
     }
     // Load plan: every lane loads its 4 pixels with ONE (unaligned) load per row -- 4 bytes grey, 12 bytes BGR -- also the
     // lanes that hold reflected columns, whose 4 (grey) bytes are then permuted.  With BORDER_REFLECT_101 a lane left of
@@ -203,16 +205,15 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     // every row wait for its own loads instead of running a row ahead: a crop has edge lanes on both sides of every work
     // unit, and its binarise kernel was latency-bound by that.)  No byte outside columns 0 .. sw-1 of the row is read.
     const bool plan = sw >= 32;   // single reflection, every offset inside the row
-    unsigned goff = 0, gsel = 0x03020100u;
-    if (plan && needed) {
-        if (c0 + 3 < 0) { goff = (unsigned)(-c0 - 3); gsel = 0x00010203u; }
-        else if (c0 >= sw) { goff = (unsigned)(2 * sw - 5 - c0); gsel = 0x00010203u; }
-        else if (c0 + 3 >= sw) { goff = (unsigned)(c0 - 2); gsel = 0x01020302u; }
-        else goff = (unsigned)c0;
+    unsigned goff = col_off(0), gsel = 0x03020100u;
+    if (plan && needed) {   // (first column of the lane's load)
+        if (c0 + 3 < 0) { goff = col_off(-c0 - 3); gsel = 0x00010203u; }
+        else if (c0 >= sw) { goff = col_off(2 * sw - 5 - c0); gsel = 0x00010203u; }
+        else if (c0 + 3 >= sw) { goff = col_off(c0 - 2); gsel = 0x01020302u; }
+        else goff = col_off(c0);
     }
-    goff *= BGR ? 3u : 1u;
     // per-lane byte offsets (unsigned: the row bases are wave-uniform, so loads/stores can use the SGPR-base + 32-bit VGPR offset form)
-    const unsigned src_off = fast ? (unsigned)(c0 * (BGR ? 3 : 1)) : 0u;
+    const unsigned src_off = fast ? col_off(c0) : col_off(0);
     // Rows are addressed through buffer resources: base in four SGPRs, the row's byte offset in one SGPR (one s_mul per row), the
     // lane's offset in a loop-invariant VGPR -- no 64-bit address arithmetic, no per-lane pointers to keep or spill.  A lane that
     // must not store gets an offset beyond the resource's size: the hardware drops its store, so the grey and mask stores need
@@ -221,7 +222,9 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     const __amdgpu_buffer_rsrc_t src_rs = make_rsrc(src, 0x7fffffffu);
     const __amdgpu_buffer_rsrc_t gray_rs = make_rsrc(o.gray, o.gray ? (unsigned)(o.gray_stride * sh) : 0u);
     const __amdgpu_buffer_rsrc_t nbr_rs = make_rsrc(o.nbr, (unsigned)nbr_plane_bytes(o.ns, sh));
-    const unsigned out_off = out_lane ? (unsigned)c0 : OOB;
+    // the grey plane's panel of this strip (hd.h::gray_col): all 64 lanes store, 256 contiguous bytes at a 256-byte boundary -- the
+    // halo lanes' bytes are the neighbouring strips' columns again (same values), or columns outside the image (never read)
+    const unsigned out_off = (unsigned)(strip * GRAY_PANEL_BYTES + 4 * lane);
     const unsigned rmask4 = lane == 63 - HR ? 0x10u : 0x30u;   // the last output lane's x+2 bit (row above) is not computed
     unsigned bit7;   // (a constant in a register, opaque to the compiler: then the AND below folds into the DPP move -- DPP operands cannot be literals)
     asm("v_mov_b32 %0, 0x80" : "=v"(bit7));
@@ -256,10 +259,17 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
             const uint2* s0 = reinterpret_cast<const uint2*>(rowbuf + flush_src);   // (lanes 56..63 read past the tiles in the second read, inside this wave's rows: their store is dropped)
             const uint2 a0 = s0[0], a1 = s0[1];       // piece l: 16 bytes
             const uint2 b0 = s0[16], b1 = s0[17];     // piece 64 + l: 32 dwords further on
-            const int so = wave_uniform(((yr_last >> 3) * (o.ns >> 4)) << 7);
+            const unsigned so = (unsigned)wave_uniform(((yr_last >> 3) * (o.ns >> 4)) << 7);
             typedef unsigned v4u __attribute__((ext_vector_type(4)));   // (non-temporal stores: written once, read much later)
-            __builtin_amdgcn_raw_buffer_store_b128((v4u){a0.x, a0.y, a1.x, a1.y}, nbr_rs, (int)flush_dst1, so, BUF_NT);
-            __builtin_amdgcn_raw_buffer_store_b128((v4u){b0.x, b0.y, b1.x, b1.y}, nbr_rs, (int)flush_dst2, so, BUF_NT);
+            // The row group's offset is added to the lanes' offsets, the scalar offset field stays 0.  A store of more than 64 bits
+            // must not be followed at once by a vector instruction that writes its data registers; the compiler's hazard
+            // recogniser inserts the wait state only for buffer stores WITHOUT a register in the scalar offset field (with one the
+            // ISA manual promises no hazard) -- and gfx950 has it all the same: with the offset in an SGPR a register copy the
+            // allocator placed right behind the second store overwrote its first data dword now and then (a selector constant
+            // in the mask plane, first dword of 16-byte pieces, only while the memory system was busy: frames >= 16 of a batch).
+            // (OOB + so < 2^32: dropped all the same.)
+            __builtin_amdgcn_raw_buffer_store_b128((v4u){a0.x, a0.y, a1.x, a1.y}, nbr_rs, (int)(flush_dst1 + so), 0, BUF_NT);
+            __builtin_amdgcn_raw_buffer_store_b128((v4u){b0.x, b0.y, b1.x, b1.y}, nbr_rs, (int)(flush_dst2 + so), 0, BUF_NT);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     };
@@ -414,16 +424,8 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
             if (S || v + 3 < v_last) nxt4 = fetch(v + 4, S);
         }
         if (EDGE && (S || plan)) g = __builtin_amdgcn_perm(g, g, gsel);   // (gsel: the identity in lanes that hold no reflected columns)
-        if (BGR && (S || (v >= Y0 && v < Y1))) {  // (BGR: the frame pass, which always has a grey plane) rows [Y0,Y1) are real rows, each loaded exactly once
-            // (steady rows: the plane's stride is a multiple of 4, so the width is, and every output lane holds 4 columns of it)
-            if (S || gray_dword) {
-                __builtin_amdgcn_raw_buffer_store_b32(g, gray_rs, (int)out_off, wave_uniform(v * (int)o.gray_stride), BUF_NT);
-            } else if (out_lane) {
-                uint8_t* q = o.gray + wave_uniform64((long long)v * o.gray_stride) + c0;
-                for (int j = 0; j < 4; j++)
-                    if (c0 + j < sw) q[j] = (uint8_t)byte_of(g, j);
-            }
-        }
+        if (BGR && (S || (v >= Y0 && v < Y1)))   // (BGR: the frame pass, which always has a grey plane) rows [Y0,Y1) are real rows, each loaded exactly once
+            __builtin_amdgcn_raw_buffer_store_b32(g, gray_rs, (int)out_off, wave_uniform(v * (int)o.gray_stride), BUF_NT);
         us2 hsum;
         {   // horizontal [1 4 6 4 1] at the lane's two even columns c0 and c0+2
             const unsigned gl = up1(g), gr = down1(g);
@@ -593,9 +595,9 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int sw, int
     // steady rows: v and v+1 are real rows of this unit ([Y0, Y1), v+1 <= sh-1), and the rows an even v completes -- pyrUp
     // rows v-4, v-3, threshold rows v-7, v-6, mask rows v-8, v-7 -- are inside the unit, at least one row away from the
     // image's top and bottom (no replicated pyrUp rows, no zeroed contour-frame rows) and not the unit's last mask row
-    // -- and the unit has the load plan and whole-dword grey stores (else no row is steady: the steady instance of the row body
-    // carries neither the byte-wise loads of images narrower than 32 columns nor byte-wise grey stores)
-    const bool steady_ok = plan && (!(BGR && o.gray) || (o.gray_stride & 3) == 0);
+    // -- and the unit has the load plan (else no row is steady: the steady instance of the row body does not carry the byte-wise
+    // loads of images narrower than 32 columns)
+    const bool steady_ok = plan;
     const int vs0 = (Y0 + 8 > 8 ? Y0 + 8 : 8) | 1, vs1 = !steady_ok ? -1 : Y1 - 1 < sh - 2 - AHEAD ? Y1 - 1 : sh - 2 - AHEAD;   // (vs0 odd: steady rows run in pairs; v + 2 is a real row: prefetched unreflected)
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -656,8 +658,8 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(OCVAR_W
     const int Y0 = chunk * ws.frame_chunk_rows;
     const int Y1 = Y0 + ws.frame_chunk_rows < ws.sh ? Y0 + ws.frame_chunk_rows : ws.sh;
     MarchOut o;
-    o.gray = ws.gray + (size_t)f * ws.W * ws.H;
-    o.gray_stride = ws.W;
+    o.gray = ws.gray + (size_t)f * gray_plane_bytes(ws.W, ws.H);
+    o.gray_stride = gray_pitch(ws.W);
     o.nbr = ws.nbr_frame + (size_t)f * nbr_plane_bytes(ws.ns, ws.sh);
     o.ns = ws.ns;
     o.roi = f;
@@ -667,8 +669,8 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(OCVAR_W
     o.err = ws.counters + CNT_ERR;
     const int w4 = wave_uniform((int)(threadIdx.x >> 6));
     const bool edge = strip == 0 || ((ws.sw - 1 - (strip * MARCH_STRIP - 4 * MARCH_HALO_L)) >> 2) <= 63;   // march_unit's left_edge || right_edge
-    if (edge) march_unit<true, true>(bgr + (size_t)f * frame_stride, row_stride, ws.sw, ws.sh, strip, Y0, Y1, o, stage[w4], rowbuf[w4], tab);
-    else march_unit<true, false>(bgr + (size_t)f * frame_stride, row_stride, ws.sw, ws.sh, strip, Y0, Y1, o, stage[w4], rowbuf[w4], tab);
+    if (edge) march_unit<true, true>(bgr + (size_t)f * frame_stride, row_stride, 0, ws.sw, ws.sh, strip, Y0, Y1, o, stage[w4], rowbuf[w4], tab);
+    else march_unit<true, false>(bgr + (size_t)f * frame_stride, row_stride, 0, ws.sw, ws.sh, strip, Y0, Y1, o, stage[w4], rowbuf[w4], tab);
 }
 
 // Odd width / height: the last column / row lies outside the even working size (opencvar.cpp:158) but is still
@@ -676,12 +678,16 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(OCVAR_W
 __global__ __launch_bounds__(256) void grey_edges_kernel(Workspace ws, const uint8_t* bgr, int row_stride, size_t frame_stride) {
     const int f = blockIdx.y;
     const uint8_t* src = bgr + (size_t)f * frame_stride;
-    uint8_t* g = ws.gray + (size_t)f * ws.W * ws.H;
+    uint8_t* g = ws.gray + (size_t)f * gray_plane_bytes(ws.W, ws.H);
+    const int pitch = gray_pitch(ws.W);
     const int n_col = ws.W > ws.sw ? ws.H : 0, n_row = ws.H > ws.sh ? ws.W : 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_col + n_row; i += gridDim.x * blockDim.x) {
         const int x = i < n_col ? ws.sw : i - n_col, y = i < n_col ? i : ws.sh;
         const uint8_t* p = src + (long long)y * row_stride + 3 * x;
-        g[(long long)y * ws.W + x] = (uint8_t)grey_of(p[0], p[1], p[2]);
+        const uint8_t v = (uint8_t)grey_of(p[0], p[1], p[2]);
+        g[(long long)y * pitch + gray_col(x)] = v;
+        // (a column within 8 of a panel's start is also kept at the end of the panel before: readers take the panel of a run's first column)
+        if (x >= GRAY_PANEL_COLS && x % GRAY_PANEL_COLS < GRAY_PANEL_LEAD) g[(long long)y * pitch + gray_col(x - GRAY_PANEL_LEAD) + GRAY_PANEL_LEAD] = v;
     }
 }
 
@@ -689,12 +695,13 @@ __global__ __launch_bounds__(256) void grey_edges_kernel(Workspace ws, const uin
 // grey plane so that no wave ever reads a half-written BGR pixel of a neighbouring strip's halo.
 __global__ __launch_bounds__(256) void grey_writeback_kernel(Workspace ws, uint8_t* bgr, int row_stride, size_t frame_stride) {
     const int f = blockIdx.y;
-    const uint8_t* g = ws.gray + (size_t)f * ws.W * ws.H;
+    const uint8_t* g = ws.gray + (size_t)f * gray_plane_bytes(ws.W, ws.H);
+    const int pitch = gray_pitch(ws.W);
     uint8_t* dst = bgr + (size_t)f * frame_stride;
     const long long n = (long long)ws.W * ws.H;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % ws.W), y = (int)(i / ws.W);
-        const uint8_t v = g[i];
+        const uint8_t v = g[(long long)y * pitch + gray_col(x)];
         uint8_t* q = dst + (long long)y * row_stride + 3 * x;
         q[0] = q[1] = q[2] = v;
     }
@@ -727,7 +734,8 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(OCVAR_W
         if (u >= n_units) break;
         const TileDesc td = ws.tiles_crop[u];
         const Roi r = ws.rois_crop[td.roi];
-        const uint8_t* src = ws.gray + (size_t)r.frame * ws.W * ws.H + (size_t)r.y0 * ws.W + r.x0;
+        const int pitch = gray_pitch(ws.W);
+        const uint8_t* src = ws.gray + (size_t)r.frame * gray_plane_bytes(ws.W, ws.H) + (size_t)r.y0 * pitch;   // (row y0 of the frame's panelled grey plane; the columns go through gray_col(r.x0 + column))
         const int Y1 = td.y0 + MARCH_CROP_ROWS < r.sh ? td.y0 + MARCH_CROP_ROWS : r.sh;
         MarchOut o;
         o.gray = nullptr;
@@ -739,7 +747,7 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(OCVAR_W
         o.n_cands = ws.counters + CNT_CROP_CANDS;
         o.cap_cands = ws.cap_crop_cands;
         o.err = ws.counters + CNT_ERR;
-        march_unit<false, true>(src, ws.W, r.sw, r.sh, td.x0, td.y0, Y1, o, stage[wave], rowbuf[wave], tab);
+        march_unit<false, true>(src, pitch, r.x0, r.sw, r.sh, td.x0, td.y0, Y1, o, stage[wave], rowbuf[wave], tab);
     }
 }
 

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(64) void decode_kernel(Workspace ws) {
                 pat[k] = (float)q.pt[k];
                 pts[k] = ws.squares[((size_t)f * ws.maxq + i) * 8 + k];
             }
-            const uint8_t* crop = ws.gray + (size_t)roi.frame * ws.W * ws.H + (size_t)roi.y0 * ws.W + roi.x0;
+            const uint8_t* plane = ws.gray + (size_t)roi.frame * gray_plane_bytes(ws.W, ws.H);
+            const int pitch = gray_pitch(ws.W);
+            auto crop_px = [=](int ix, int iy) -> int { return plane[(size_t)(roi.y0 + iy) * pitch + gray_col(roi.x0 + ix)]; };
             for (int j = 0; j < T; j++) {   // in order: the orient 2/4 corner rotation leaks into the next template (D4)
                 const TemplateRec t = ws.templates[j];
                 double M[9];
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64) void decode_kernel(Workspace ws) {
                     const int ci = p / t.width, cj = t.width - 1 - p % t.width;
                     int cx, cy;
                     if (code_cell(ci * t.width + cj, t.width, t.height, &cx, &cy))
-                        v = warp_sample(crop, roi.w, roi.h, ws.W, M, cx + 1, cy + 1) > 100;
+                        v = warp_sample_px(crop_px, roi.w, roi.h, M, cx + 1, cy + 1) > 100;
                 }
                 const long long bit = (long long)__ballot(v);
                 const int orient = match_orient(bit, t);

@@ -72,7 +72,9 @@ OCVAR_HD void invert_map(const float* m32, double* M) {
 }
 
 // One destination pixel (x,y) of cvWarpPerspective(INTER_LINEAR, fill 0) on a single-channel crop.
-OCVAR_HD int warp_sample(const uint8_t* crop, int cw, int ch, int stride, const double* M, int x, int y) {
+// (px(ix, iy): the crop's pixel at column ix, row iy -- the device reads the panelled grey plane through it)
+template <class Px>
+OCVAR_HD int warp_sample_px(Px px, int cw, int ch, const double* M, int x, int y) {
     const double X0 = M[0] * 0 + M[1] * y + M[2];
     const double Y0 = M[3] * 0 + M[4] * y + M[5];
     const double W0 = M[6] * 0 + M[7] * y + M[8];
@@ -92,11 +94,14 @@ OCVAR_HD int warp_sample(const uint8_t* crop, int cw, int ch, int stride, const 
     }
     const bool x0ok = ix >= 0 && ix < cw, x1ok = ix + 1 >= 0 && ix + 1 < cw;
     const bool y0ok = iy >= 0 && iy < ch, y1ok = iy + 1 >= 0 && iy + 1 < ch;
-    const int p00 = (x0ok && y0ok) ? crop[(long long)iy * stride + ix] : 0;
-    const int p01 = (x1ok && y0ok) ? crop[(long long)iy * stride + ix + 1] : 0;
-    const int p10 = (x0ok && y1ok) ? crop[(long long)(iy + 1) * stride + ix] : 0;
-    const int p11 = (x1ok && y1ok) ? crop[(long long)(iy + 1) * stride + ix + 1] : 0;
+    const int p00 = (x0ok && y0ok) ? px(ix, iy) : 0;
+    const int p01 = (x1ok && y0ok) ? px(ix + 1, iy) : 0;
+    const int p10 = (x0ok && y1ok) ? px(ix, iy + 1) : 0;
+    const int p11 = (x1ok && y1ok) ? px(ix + 1, iy + 1) : 0;
     return (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + 16384) >> 15;
+}
+OCVAR_HD int warp_sample(const uint8_t* crop, int cw, int ch, int stride, const double* M, int x, int y) {
+    return warp_sample_px([=](int ix, int iy) -> int { return crop[(long long)iy * stride + ix]; }, cw, ch, M, x, y);
 }
 
 // The bit of flat index k (k = i*tw + j of acArray2DToBit's arr[i*w+j]) lives at pixel (k % ws, k / ws) of

@@ -62,6 +62,23 @@ OCVAR_HD unsigned nbr_col_off(int x) {
 }
 OCVAR_HD long long nbr_plane_bytes(int ns, int sh) { return (long long)ns * ((sh + 7) & ~7); }
 
+// The grey plane is stored in PANELS: panel p of a row holds columns 240 p - 8 .. 240 p + 247 in 256 bytes -- the 256 columns one
+// wave of the frame binarise kernel converts (its 240 output columns and the 8-column halo on either side), so that every grey
+// store of that kernel is 256 contiguous bytes at a 256-byte boundary: whole 64-byte sectors.  (Stored row-major at the image's
+// own pitch, a wave's 240 bytes began at 240 s: five sectors touched, two of them shared with the neighbouring strips' waves; the
+// partial sectors made the grey byte the dearest of the five the kernel moves per pixel -- tools/micro/strip_stream.hip: the same
+// loads and stores take 2.9 ms per 1024 frames with rows stored whole and 2.2 ms with sector-aligned strips.)  Neighbouring panels
+// overlap by 16 columns, so any run of up to 9 consecutive columns lies inside one panel: a reader takes the panel of the run's
+// first column.  Row pitch = panels x 256 bytes; the bytes of columns outside the image are never read.
+constexpr int GRAY_PANEL_COLS = 240, GRAY_PANEL_BYTES = 256, GRAY_PANEL_LEAD = 8;
+OCVAR_HD int gray_pitch(int W) { return ((W + GRAY_PANEL_COLS - 1) / GRAY_PANEL_COLS) * GRAY_PANEL_BYTES; }
+OCVAR_HD long long gray_plane_bytes(int W, int H) { return (long long)gray_pitch(W) * H; }
+// byte offset of column x (>= 0) in its row, in the panel x belongs to (consecutive columns up to x + 8 follow contiguously)
+OCVAR_HD unsigned gray_col(int x) {
+    const unsigned p = (unsigned)x / (unsigned)GRAY_PANEL_COLS;
+    return p * (unsigned)(GRAY_PANEL_BYTES - GRAY_PANEL_COLS) + (unsigned)x + (unsigned)GRAY_PANEL_LEAD;
+}
+
 // One region of interest handed to the square finder: a whole frame (frame pass) or the clipped
 // bounding box of a frame-pass quad (crop pass, opencvar.cpp:682-693).
 struct Roi {

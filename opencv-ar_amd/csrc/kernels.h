@@ -13,6 +13,7 @@ constexpr int MAXM = OCVAR_MAX_MARKERS;    // markers kept per frame (tracked + 
 constexpr int MAXT = OCVAR_MAX_TEMPLATES;
 constexpr int MARCH_HALO_L = 2, MARCH_HALO_R = 2;   // halo lanes (4 pixels each) left / right of a strip's output lanes
 constexpr int MARCH_STRIP = 4 * (64 - MARCH_HALO_L - MARCH_HALO_R);   // 240 output columns of one wave's strip in the binarise kernel (256 loaded)
+static_assert(MARCH_STRIP == GRAY_PANEL_COLS && 4 * MARCH_HALO_L == GRAY_PANEL_LEAD && 4 * 64 == GRAY_PANEL_BYTES, "a grey panel is what one wave of the frame kernel converts");
 constexpr int MARCH_CROP_ROWS = 256;       // rows per work unit in the crop pass (even)
 constexpr int MARCH_STAGE = 512;           // border starts a wave stages in LDS between two appends to the global list
 constexpr int BACK_STEPS = 32;             // backward look of an outer start before it follows its border
@@ -65,7 +66,7 @@ struct Workspace {
     int short_blocks, crop_blocks;           // grids of follower tier 1 and of the crop binarise kernel (scaled with the batch)
     int frame_strips, frame_chunks, frame_chunk_rows;  // binarise work decomposition of a frame
     // device buffers
-    uint8_t* gray;          // [B][H][W]
+    uint8_t* gray;          // [B][H][gray_pitch(W)]: panels of 256 bytes (hd.h::gray_col)
     uint8_t* nbr_frame;     // [B][sh][sw]
     uint8_t* nbr_crop;      // crop pool
     StartCand* cands_frame;

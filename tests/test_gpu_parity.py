@@ -515,3 +515,29 @@ def test_camera_with_lens_distortion(oa):
         ref_pin, _, _ = H.oracle_registration(frames[f], tpls, pin)
         moved += sum(np.abs(np.array(a.glMatrix) - np.array(b.glMatrix)).max() > 1e-3 for a, b in zip(ref_m, ref_pin))
     assert moved >= 1   # the coefficients change the pose: the test would notice a solver that ignores them
+
+
+@pytest.mark.gpu
+def test_planes_of_every_frame_of_a_busy_batch(oa):
+    """Grey plane and neighbour masks of ALL frames of a batch that keeps the memory system busy (64 full-HD frames): a store
+    whose data registers were overwritten too early corrupted mask words only from the 16th frame of a batch on -- every
+    small-batch test was green (the buffer stores' scalar offset field)."""
+    cfg = H.synth_config(3)
+    uniq, B = 4, 64
+    base = np.stack([H.synth_frame(cfg, i, None)[0] for i in range(uniq)])
+    det, tpls, cam = make_detector(oa, cfg, None, B)
+    import torch
+    d = torch.from_numpy(base).cuda().repeat(B // uniq, 1, 1, 1).contiguous()
+    torch.cuda.synchronize()
+    w, h = cfg.width, cfg.height
+    refs = []
+    for u in range(uniq):
+        _, _, grey = H.oracle_registration(base[u], tpls, cam)
+        g_ref = np.ascontiguousarray(grey[..., 0])
+        refs.append((g_ref, H.neighbour_masks(H.oracle_binarise(g_ref))))
+    for rep in range(2):
+        markers, counts = det.detect_device(d.data_ptr(), w, h, B)
+        assert all(counts[f] == counts[f % uniq] for f in range(B))
+    for f in range(B):
+        assert np.array_equal(det.debug_gray(f, w, h), refs[f % uniq][0]), f
+        assert np.array_equal(det.debug_masks(f, w, h), refs[f % uniq][1]), f

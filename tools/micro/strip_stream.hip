@@ -9,17 +9,19 @@
 typedef unsigned v3u __attribute__((ext_vector_type(3)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-template <int PX, int AHEAD>
+template <int PX, int AHEAD, int MODE>   // MODE bits: 1 grey stores, 2 mask stores, 4 loads without the non-temporal... (plain), 8: 16-byte aligned 4-dword loads
 __global__ __launch_bounds__(64) void strip_kernel(const unsigned char* bgr, unsigned char* grey, unsigned char* mask, int W, int H, int chunk_rows, int strips, int chunks, int n_frames) {
     const int lane = threadIdx.x;
     const int unit = blockIdx.x;
     const int per_frame = strips * chunks;
     if (unit >= per_frame * n_frames) return;
     const int f = unit / per_frame, rem = unit % per_frame, chunk = rem / strips, strip = rem % strips;
-    constexpr int OUTC = 64 * PX - 16;
-    const int c0 = strip * OUTC - 8 + lane * PX;   // first column of the lane
+    // MODE & 4: strips of 64 * PX columns side by side without halo lanes (every store of a wave covers whole, aligned 64-byte sectors)
+    constexpr int HALO = (MODE & 4) ? 0 : (MODE & 16) ? 16 : (MODE & 32) ? 32 : 8;   // columns each side
+    constexpr int OUTC = 64 * PX - 2 * HALO;
+    const int c0 = strip * OUTC - HALO + lane * PX;   // first column of the lane
     const bool in_img = c0 >= 0 && c0 + PX <= W;
-    const bool out_lane = in_img && lane * PX >= 8 && lane * PX < 64 * PX - 8;
+    const bool out_lane = in_img && lane * PX >= HALO && lane * PX < 64 * PX - HALO;
     const unsigned char* src = bgr + (size_t)f * W * H * 3;
     unsigned char* g = grey + (size_t)f * W * H;
     unsigned char* m = mask + (size_t)f * W * H;
@@ -51,15 +53,16 @@ __global__ __launch_bounds__(64) void strip_kernel(const unsigned char* bgr, uns
                 for (int k = 0; k < NV; k++) q[a][k] = q[a + 1][k];
             const int yn = yy + AHEAD + 1 < hi ? yy + AHEAD + 1 : hi - 1;
             fetch(yn, q[AHEAD]);
-            if (out_lane && yy >= y0 && yy < y1 && yy < hi) {
+            if ((MODE & 1) && out_lane && yy >= y0 && yy < y1 && yy < hi) {
 #pragma unroll
-                for (int k = 0; k < NV; k++) __builtin_nontemporal_store(gw[k], reinterpret_cast<unsigned*>(g + (size_t)yy * W + c0 + 4 * k));
+                for (int k = 0; k < NV; k++) { if (MODE & 8) *reinterpret_cast<unsigned*>(g + (size_t)yy * W + c0 + 4 * k) = gw[k]; else __builtin_nontemporal_store(gw[k], reinterpret_cast<unsigned*>(g + (size_t)yy * W + c0 + 4 * k)); }
             }
 #pragma unroll
             for (int k = 0; k < NV; k++) acc[r * NV + k] = gw[k] ^ (gw[k] >> 3);
         }
         // mask rows y .. y+7 of this lane's PX columns: 8 * PX bytes; stored as 16-byte pieces, contiguous across lanes per instruction
-        if (out_lane && y >= y0 && y + 8 <= y1) {
+        if (!(MODE & 3)) { unsigned z = 0; for (int i = 0; i < 8 * NV; i++) z |= acc[i]; if (z == 0x12345u) g[0] = 1; }
+        if ((MODE & 2) && out_lane && y >= y0 && y + 8 <= y1) {
             unsigned char* base = m + ((size_t)(y >> 3) * (W >> 4) << 7) + ((size_t)(c0 >> 4) << 7) + (size_t)(c0 & 15) * 8;
 #pragma unroll
             for (int k = 0; k < (8 * NV) / 4; k++)
@@ -68,15 +71,16 @@ __global__ __launch_bounds__(64) void strip_kernel(const unsigned char* bgr, uns
     }
 }
 
-template <int PX, int AHEAD>
+template <int PX, int AHEAD, int MODE>
 static double run(const unsigned char* bgr, unsigned char* grey, unsigned char* mask, int W, int H, int chunk_rows, int n) {
-    constexpr int OUTC = 64 * PX - 16;
+    constexpr int HALO = (MODE & 4) ? 0 : (MODE & 16) ? 16 : (MODE & 32) ? 32 : 8;
+    constexpr int OUTC = 64 * PX - 2 * HALO;
     const int strips = (W + OUTC - 1) / OUTC, chunks = (H + chunk_rows - 1) / chunk_rows;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     double best = 1e9;
     for (int rep = 0; rep < 6; rep++) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((strip_kernel<PX, AHEAD>), dim3(strips * chunks * n), dim3(64), 0, 0, bgr, grey, mask, W, H, chunk_rows, strips, chunks, n);
+        hipLaunchKernelGGL((strip_kernel<PX, AHEAD, MODE>), dim3(strips * chunks * n), dim3(64), 0, 0, bgr, grey, mask, W, H, chunk_rows, strips, chunks, n);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep > 0 && ms < best) best = ms;
@@ -90,13 +94,20 @@ int main(int argc, char** argv) {
     hipMalloc(&bgr, (size_t)n * W * H * 3); hipMalloc(&grey, (size_t)n * W * H); hipMalloc(&mask, (size_t)n * W * H + (1 << 20));
     hipMemset(bgr, 7, (size_t)n * W * H * 3);
     const double bytes = 5.0 * W * H * n;
-    for (int chunk_rows : {1080, 544, 272}) {
-        double t;
-        t = run<4, 1>(bgr, grey, mask, W, H, chunk_rows, n); printf("4 px/lane, 1 row ahead,  %4d-row chunks: %7.3f ms  %.2f TB/s\n", chunk_rows, t, bytes / t / 1e9);
-        t = run<4, 2>(bgr, grey, mask, W, H, chunk_rows, n); printf("4 px/lane, 2 rows ahead, %4d-row chunks: %7.3f ms  %.2f TB/s\n", chunk_rows, t, bytes / t / 1e9);
-        t = run<4, 4>(bgr, grey, mask, W, H, chunk_rows, n); printf("4 px/lane, 4 rows ahead, %4d-row chunks: %7.3f ms  %.2f TB/s\n", chunk_rows, t, bytes / t / 1e9);
-        t = run<8, 1>(bgr, grey, mask, W, H, chunk_rows, n); printf("8 px/lane, 1 row ahead,  %4d-row chunks: %7.3f ms  %.2f TB/s\n", chunk_rows, t, bytes / t / 1e9);
-        t = run<8, 2>(bgr, grey, mask, W, H, chunk_rows, n); printf("8 px/lane, 2 rows ahead, %4d-row chunks: %7.3f ms  %.2f TB/s\n", chunk_rows, t, bytes / t / 1e9);
-    }
+    const int chunk_rows = 544;
+    double t;
+    t = run<4, 2, 0>(bgr, grey, mask, W, H, chunk_rows, n); printf("reads only            : %7.3f ms  %.2f TB/s of reads (3 B/px)\n", t, 3.0 * W * H * n / t / 1e9);
+    t = run<4, 2, 1>(bgr, grey, mask, W, H, chunk_rows, n); printf("reads + grey stores   : %7.3f ms  %.2f TB/s (4 B/px)\n", t, 4.0 * W * H * n / t / 1e9);
+    t = run<4, 2, 2>(bgr, grey, mask, W, H, chunk_rows, n); printf("reads + mask stores   : %7.3f ms  %.2f TB/s (4 B/px)\n", t, 4.0 * W * H * n / t / 1e9);
+    t = run<4, 2, 3>(bgr, grey, mask, W, H, chunk_rows, n); printf("reads + both          : %7.3f ms  %.2f TB/s (5 B/px)\n", t, bytes / t / 1e9);
+    t = run<4, 2, 5>(bgr, grey, mask, W, H, chunk_rows, n); printf("aligned strips: reads + grey : %7.3f ms  %.2f TB/s (4 B/px)\n", t, 4.0 * W * H * n / t / 1e9);
+    t = run<4, 2, 6>(bgr, grey, mask, W, H, chunk_rows, n); printf("aligned strips: reads + mask : %7.3f ms  %.2f TB/s (4 B/px)\n", t, 4.0 * W * H * n / t / 1e9);
+    t = run<4, 2, 7>(bgr, grey, mask, W, H, chunk_rows, n); printf("aligned strips: reads + both : %7.3f ms  %.2f TB/s (5 B/px)\n", t, bytes / t / 1e9);
+    t = run<4, 2, 9>(bgr, grey, mask, W, H, chunk_rows, n); printf("240-col strips, PLAIN grey stores (no nt): reads + grey : %7.3f ms\n", t);
+    t = run<4, 2, 11>(bgr, grey, mask, W, H, chunk_rows, n); printf("240-col strips, PLAIN grey stores: reads + both : %7.3f ms  %.2f TB/s\n", t, bytes / t / 1e9);
+    t = run<4, 2, 19>(bgr, grey, mask, W, H, chunk_rows, n); printf("224-col strips (32-byte aligned), nt: reads + both : %7.3f ms  %.2f TB/s\n", t, bytes / t / 1e9);
+    t = run<4, 2, 35>(bgr, grey, mask, W, H, chunk_rows, n); printf("192-col strips (64-byte aligned), nt: reads + both : %7.3f ms  %.2f TB/s\n", t, bytes / t / 1e9);
+    t = run<8, 2, 0>(bgr, grey, mask, W, H, chunk_rows, n); printf("8 px: reads only      : %7.3f ms  %.2f TB/s of reads\n", t, 3.0 * W * H * n / t / 1e9);
+    t = run<8, 2, 3>(bgr, grey, mask, W, H, chunk_rows, n); printf("8 px: reads + both    : %7.3f ms  %.2f TB/s (5 B/px)\n", t, bytes / t / 1e9);
     return 0;
 }
