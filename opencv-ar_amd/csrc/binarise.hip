@@ -575,13 +575,14 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int x_org /
                     // belong to the same 4-connected background region and NE comes earlier).
                     if ((!S && (y < Y0 || y >= Y1)) || (__ballot((st & 0xf0fu) != 0) & (EDGE ? ~0ull : OUT_LANES)) == 0) continue;
 #pragma nounroll   // (rare rows, and the steady loop holds eight copies of this: kept small)
-                    for (int j = 0; j < 4; j++) {
-                        const int type = ((st >> j) & 1u) ? 0 : ((st >> (8 + j)) & 1u) ? 1 : -1;
-                        const unsigned long long mask = __ballot(type >= 0) & (EDGE ? ~0ull : OUT_LANES);
+                    for (int j = 0; j < 4; j++) {   // (two vector instructions per pixel position that has no start: this runs on every third row)
+                        const unsigned hit = st & (0x101u << j);   // pixel j: bit j an outer start, bit 8 + j a hole start (never both: foreground / background)
+                        const unsigned long long mask = __ballot(hit != 0) & (EDGE ? ~0ull : OUT_LANES);
                         if (!mask) continue;
                         const int n = __popcll(mask);
                         if (staged + n > MARCH_STAGE) flush();
-                        if ((mask >> lane) & 1ull) stage[staged + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)(y * o.ns + c0 + j) | ((unsigned)type << 31);
+                        if ((mask >> lane) & 1ull)
+                            stage[staged + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)(y * o.ns + c0 + j) | (hit >> 8 ? 0x80000000u : 0u);
                         staged += n;
                     }
                 }
