@@ -26,8 +26,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # behind another stream's (measured: 166 k frames/s instead of 200 k for four contexts on the runtime's default).  Read by the
 # runtime when it initialises, like the variable above; INTEGRATION.md tells C/C++ callers the same.  12: four context streams, the
 # null stream, and -- in multi-rank runs -- the gather stream and RCCL's own streams each get a queue (one-GPU run: 5 .. 12 queues all give
-# ~195 k; with RCCL initialised 6 / 8 / 12 queues give 155 / 182 / 195 k).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+# ~195 k; with RCCL initialised 6 / 8 / 12 queues give 155 / 182 / 195 k).  Five contexts and RCCL (round 3, one-rank rehearsal with
+# the per-step gather): 12 / 16 / 24 queues give 213.6 / 213.9 / 218.8 k against 232 k without the gather -- 24 for multi-rank runs.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("OCVAR_BENCH_FORCE_DIST") else "12")
 
 import numpy as np
 
@@ -204,6 +205,8 @@ def main():
     # cost 5 %: the collective sits in a hardware queue behind a context's kernels, and meanwhile nothing is collected or
     # re-enqueued.)
     gathering = world > 1 or force_dist
+    dist_skip = os.environ.get("OCVAR_BENCH_DIST_SKIP", "") if force_dist else ""   # one-rank rehearsal only: "blocks", "gather" or both -- what the parts of the distributed path cost
+    gather_host_s = [0.0]   # host time spent issuing the gathers (the contexts are not re-enqueued meanwhile)
     gather_stream = torch.cuda.Stream(priority=-1) if gathering else None
     gather_done = [None, None]
 
@@ -213,7 +216,7 @@ def main():
         if gather_done[buf] is not None:
             streams[i].wait_event(gather_done[buf])
         dets[i].enqueue_device(d_frames.data_ptr() + o * frame_bytes, W, Hh, n)
-        if gathering:
+        if gathering and "blocks" not in dist_skip:
             dets[i].results_to_device(d_res[buf].data_ptr() + o * GATHER_K * S.MARKER_BYTES,
                                       d_res[buf].data_ptr() + nbytes_m + 4 * o, streams[i].cuda_stream, per_frame=GATHER_K)
         last[i] = n
@@ -242,11 +245,13 @@ def main():
                     enqueue(i, n, (k + 1) % 2, skip=0 if k < K - 1 else first[i])
                 else:
                     last.pop(i)
-            if gathering:   # one gather of the ranks' result blocks per step (the launches that filled this buffer are complete)
+            if gathering and "gather" not in dist_skip:   # one gather of the ranks' result blocks per step (the launches that filled this buffer are complete)
+                t_g = time.perf_counter()
                 with torch.cuda.stream(gather_stream):
                     blocks = S.gather_blocks(d_res[k % 2], rank, world, dist)
                     gather_done[k % 2] = torch.cuda.Event()
                     gather_done[k % 2].record(gather_stream)
+                gather_host_s[0] += time.perf_counter() - t_g
                 if rank == 0 and not timed:   # warm-up only: the gathered blocks decode and no frame has more markers than a block keeps
                     gather_stream.synchronize()
                     got = S.unpack(blocks, B, oa.MARKER_DTYPE, GATHER_K)
@@ -350,7 +355,8 @@ def main():
                                    f"{'2x2' if names else '2x2/3x3/4x4 x 4 rotations'}, batch {B} frames/GPU/step "
                                    f"({uniq} distinct) in {NS} stream(s)" + (f", at most {args.gate} binarise kernels at once" if gate is not None else "") + ", stateless", "frames_per_step_per_gpu": B, "streams": NS,
                        "library": oa.build_info(), "tuning": args.tune or "defaults",
-                       "parallelism": f"frame-sharded x{world}" + ((f", RCCL gather of CvarMarker arrays ({GATHER_K} records per frame + counts)" if backend == "nccl" else f", {backend} rehearsal of the gather (ranks share devices)") if world > 1 else "")},
+                       "parallelism": f"frame-sharded x{world}" + ((f", RCCL gather of CvarMarker arrays ({GATHER_K} records per frame + counts)" if backend == "nccl" else f", {backend} rehearsal of the gather (ranks share devices)") if world > 1 else ""),
+                       "gather_host_ms_per_step": round(1e3 * gather_host_s[0] / max(1, args.steps + args.warmup), 3) if gathering else None},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "launch_ms": round(float(stage_ms[dom[1]]), 4), "alg_bytes_per_launch": round(dom[2]),
