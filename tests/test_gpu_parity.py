@@ -247,6 +247,20 @@ def test_textured_background_and_odd_size(oa):
         check_frame(det, f, frames[f], tpls, cam, markers, counts)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("width,height", [(487, 365), (729, 243), (961, 541)])
+def test_odd_sizes_whose_last_column_or_row_begins_a_grey_panel(oa, width, height):
+    """The grey plane is stored in panels of 240 columns that overlap by 16 (hd.h::gray_col): the odd last column -- greyed by its
+    own kernel -- of these widths lies within 8 columns of a panel's start, so it is kept twice; crops reach over it."""
+    cfg = H.synth_config(3, textured=1, width=width, height=height, grid_x=max(1, width // 240), grid_y=max(1, height // 240),
+                         side_min=70, side_max=110)
+    det, tpls, cam = make_detector(oa, cfg, None, 2)
+    frames = np.stack([H.synth_frame(cfg, f)[0] for f in range(2)])
+    markers, counts = det.detect_host(frames.copy())
+    for f in range(2):
+        check_frame(det, f, frames[f], tpls, cam, markers, counts)
+
+
 def test_config5_4k_jitter_and_occlusion(oa):
     cfg = H.synth_config(5)
     det, tpls, cam = make_detector(oa, cfg, None, 1)
