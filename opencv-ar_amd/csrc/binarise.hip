@@ -5,15 +5,19 @@
 // also the BGR2GRAY of cvarArMultRegistration (opencvar.cpp:624-627) -- and the local part of cvFindContours
 // (opencvar.cpp:183-184): zeroing the 1-px frame and spotting where a border can begin.
 //
-// "Wave march": one 64-lane wavefront owns a strip of 256 columns (4 pixels per lane: 240 output columns + an
-// 8-column halo on each side) and walks down a chunk of rows.  Everything vertical lives in registers as
-// sliding windows (5 rows of the horizontal pyrDown sums, 3 rows of the horizontally up-sampled pyramid,
-// 8 pyrUp rows as one byte per row in two registers per pixel, the table outputs of the last two threshold rows);
-// everything horizontal is a 4-pixel packed word handed to the neighbour lane with a DPP wave shift.  One (unaligned)
-// load per lane and row, reflected columns included; the image itself never goes through LDS, which only holds a
-// 128-entry table (threshold-bit window -> neighbour-mask contributions and border-start nibbles), 8 mask rows per
-// wave on their way to whole 16x8 tiles, and the staged border starts.  The row body exists in several instances
-// (steady rows in odd/even pairs, strips away from the image edges) so that the hot loop carries no range tests.
+// "Wave march": one 64-lane wavefront (a workgroup of its own) owns a strip of 256 columns (4 pixels per lane: 240 output
+// columns + an 8-column halo on each side) and walks down a chunk of rows.  Everything vertical lives in registers and nothing
+// is a window that is shifted: the vertical pyrDown is two accumulators, the vertical pyrUp two running sums (times four, so a
+// finished pixel is the high byte of its sum), the last 8 pyrUp rows a ring of bytes in two registers per pixel that swap names
+// every four rows, the table outputs of the last two threshold rows three registers; everything horizontal is a 4-pixel packed
+// word handed to the neighbour lane with a DPP wave shift.  One (unaligned) buffer load per lane and row, reflected columns
+// included, two rows under way beyond the current one; rows are addressed through buffer resources (scalar row offset,
+// loop-invariant lane offset, stores masked by range).  The image itself never goes through LDS, which only holds a 128-entry
+// table (threshold-bit window -> neighbour-mask contributions and border-start nibbles), 8 mask rows per wave on their way to
+// whole 16x8 tiles, and the staged border starts.  The grey plane is stored in 256-byte panels, one per strip (hd.h::gray_col):
+// every store of the kernel is whole 64-byte sectors.  The row body exists in several instances (steady rows in groups of four
+// with the ring's position known, strips away from the image edges) so that the hot loop carries no range tests; the filters'
+// border rules at the image edges are per-lane byte selectors.
 // HBM traffic per pixel: 3 B read + 1 B grey + 1 B mask (frame mode).
 // The arithmetic is the integer arithmetic of the definition, so the output is bit-identical:
 //   pyrDown  [1 4 6 4 1]^2, (v+128)>>8, BORDER_REFLECT_101        pyrUp  [1 6 1]/[4 4], (v+32)>>6, borders -1->1, n->n-1
