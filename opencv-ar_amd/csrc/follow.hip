@@ -963,8 +963,14 @@ __global__ __launch_bounds__(FOLLOW_THREADS) void follow_mid_kernel(Workspace ws
             }
             have = false;
         }
-        // borders stored in the lanes' slabs: statistics, approximation and filter by the whole wave, one at a time
+        // borders stored in the lanes' slabs: statistics, approximation and filter by the whole wave, one at a time.  While a
+        // border is finished the wave's other walks stand still (at the benchmark's launch size finishing is half of this kernel's
+        // cycles on frames and a third on crops), so nothing is fetched from memory per border that a lane already holds: the
+        // ROI's size comes from the walking lane's registers, and every retiring lane loads its crop's best start once, all of
+        // them together, before the loop (a value a moment old only prunes a little less: the winner is chosen by atomicMin).
         unsigned long long todo = __ballot(route == 3);
+        unsigned my_best = 0xffffffffu;
+        if (CROP && route == 3) my_best = (unsigned)(ws.best_crop[c.roi] >> 32);
         if (todo) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // each lane stored its own slab; now every lane reads them
         while (todo) {
             const int L = __ffsll((long long)todo) - 1;
@@ -975,9 +981,11 @@ __global__ __launch_bounds__(FOLLOW_THREADS) void follow_mid_kernel(Workspace ws
             cl.is_hole = __builtin_amdgcn_readlane(c.is_hole, L);
             const int nl = __builtin_amdgcn_readlane(slab_npts, L);
             const unsigned* sl = wave_slabs + (size_t)L * SLAB_STRIDE;
-            const PlaneRef pll = plane_of<CROP>(ws, cl.roi);
+            PlaneRef pll = pl;   // (of the finish only the ROI's size is used: the quad filter's border rule)
+            pll.img_w = __builtin_amdgcn_readlane(pl.img_w, L);
+            pll.img_h = __builtin_amdgcn_readlane(pl.img_h, L);
             // crops: a border that starts behind the crop's best quad cannot replace it
-            const bool beaten = CROP && uni((unsigned)(ws.best_crop[cl.roi] >> 32)) < (unsigned)cl.pos;
+            const bool beaten = CROP && (unsigned)__builtin_amdgcn_readlane((int)my_best, L) < (unsigned)cl.pos;
             if (!beaten) wave_finish_packed<CROP, true>(ws, cl, pll, sl, nl, parked[wave], &scratch[wave]);
             PROF_ADD(6, 1);
         }

@@ -22,6 +22,9 @@ W, Hh = cfg.width, cfg.height
 det = oa.Detector(W, Hh, max_batch=B)
 det.set_templates(oa.load_templates([os.path.join(oa.TEMPLATE_DIR, n + ".png") for n in H.TEMPLATE_ORDER]))
 det.set_camera(oa.default_camera(W, Hh))
+gate = oa.Gate(2, 0) if os.environ.get("PROF_GATE") == "1" else None   # PROF_GATE=1: the launch geometry of a context that shares the GPU (a quarter of tier 2's grid)
+if gate is not None:
+    det.set_gate(gate)
 d = torch.from_numpy(base).cuda().repeat(B // uniq, 1, 1, 1).contiguous()
 torch.cuda.synchronize()
 for _ in range(2):
