@@ -428,6 +428,8 @@ __device__ void march_unit(const uint8_t* src, long long src_stride, int x_org /
             if (S || v + 3 < v_last) nxt4 = fetch(v + 4, S);
         }
         if (EDGE && (S || plan)) g = __builtin_amdgcn_perm(g, g, gsel);   // (gsel: the identity in lanes that hold no reflected columns)
+        // (a 32-bit store reads its data register as it issues: unlike the 128-bit tile stores in flush_rows it may keep the row's
+        // offset in the scalar offset field; test_planes_of_every_frame_of_a_busy_batch compares the grey plane too)
         if (BGR && (S || (v >= Y0 && v < Y1)))   // (BGR: the frame pass, which always has a grey plane) rows [Y0,Y1) are real rows, each loaded exactly once
             __builtin_amdgcn_raw_buffer_store_b32(g, gray_rs, (int)out_off, wave_uniform(v * (int)o.gray_stride), BUF_NT);
         us2 hsum;
