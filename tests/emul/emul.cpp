@@ -352,3 +352,7 @@ extern "C" int emul_trace_tiled(const uint8_t* nbr, int ns, int sh, int cpos, in
     info[0] = r.npts; info[1] = r.steps; info[2] = (int)t.loads;
     return r.status;
 }
+
+// ---- layout of the panelled grey plane (hd.h) ---------------------------------------------------------------------------
+extern "C" int emul_gray_pitch(int W) { return ocvar::gray_pitch(W); }
+extern "C" unsigned emul_gray_col(int x) { return ocvar::gray_col(x); }

@@ -188,3 +188,25 @@ def test_pose_with_lens_distortion(emul):
     g3 = np.zeros(16)
     o.orc_square_to_matrix(P(sq), C.byref(pin), C.c_double(ratio), P(g3))
     assert np.abs(g3 - g1).max() > 1e-3
+
+
+def test_grey_plane_panels(emul):
+    """hd.h::gray_col / gray_pitch: panel p of a row holds columns 240 p - 8 .. 240 p + 247 in 256 bytes (what one wave of the frame
+    kernel converts).  The properties the readers rely on: home offsets are distinct and inside the row; from any column the next
+    8 columns follow contiguously (a crop lane's 4-byte load, decode's two neighbouring samples); a column within 8 of a panel's
+    start is the 8-column tail of the panel before it shifted by one panel (where the frame kernel's halo lanes -- and the
+    odd-column kernel -- keep the second copy)."""
+    import ctypes as C
+    emul.emul_gray_col.restype = C.c_uint
+    for W in (16, 239, 240, 241, 243, 480, 487, 640, 1001, 1920, 3840):
+        pitch = emul.emul_gray_pitch(W)
+        assert pitch % 256 == 0 and pitch >= ((W + 239) // 240) * 256
+        offs = [emul.emul_gray_col(x) for x in range(W)]
+        assert len(set(offs)) == W and max(offs) < pitch and min(offs) == 8
+        for x in range(W):
+            p = x // 240
+            assert offs[x] == p * 256 + (x - 240 * p) + 8
+            # the 256 bytes of panel p start at column 240 p - 8: a run that begins at x stays inside panel p for 9 columns
+            assert offs[x] + 8 <= p * 256 + 255
+            if x >= 240 and x % 240 < 8:   # second copy: same column, seen from the panel before
+                assert emul.emul_gray_col(x - 8) + 8 == (p - 1) * 256 + 248 + x % 240
