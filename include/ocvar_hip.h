@@ -150,7 +150,7 @@ int ocvar_hip_results_to_device_ex(OcvarHip* ctx, OcvarMarker* d_markers, int* d
 
 /* Several contexts on one GPU as one detector: n_contexts contexts of chunk_frames frames each (own streams, one shared gate
  * of gate_width binarise kernels, 0: none) detect a device-resident array of any number of frames chunk by chunk, every context
- * with one chunk in flight (csrc/pipe.hip: the schedule of bench.py behind the C ABI -- four contexts, gate 2: ~1.4x the
+ * with one chunk in flight (csrc/pipe.hip: the schedule of bench.py behind the C ABI -- four or five contexts, gate 2: ~1.9x the
  * frames/s of one context).  Stateless; results in frame order like ocvar_hip_detect_device.  No counterpart in the reference
  * (one frame per call); the many-frames form of its per-frame loop, samples/ARTest.cpp:43-82. */
 typedef struct OcvarPipe OcvarPipe;
