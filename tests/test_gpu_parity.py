@@ -59,7 +59,8 @@ def check_frame(det, f, frame_bgr, tpls, cam, markers, counts, prev=None):
         assert np.abs(m["square"] - np.array(r.square)).max() <= CORNER_TOL
         assert m["aspectRatio"] == r.aspectRatio
         g = np.array(r.glMatrix)
-        assert np.abs(m["glMatrix"] - g).max() <= POSE_RTOL * max(1.0, np.abs(g).max())
+        assert np.abs(m["glMatrix"] - g).max() <= POSE_RTOL * max(1.0, np.abs(g).max()), (
+            "pose", f, k, float(np.abs(m["glMatrix"] - g).max()), float(np.abs(g).max()), np.array(r.square).tolist(), g.tolist(), m["glMatrix"].tolist())
     return ref_m, len(ref_c)
 
 
