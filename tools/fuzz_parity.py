@@ -30,6 +30,9 @@ for s in range(n_scenes):
         # lengths 6:1 -- the planar pose fit is so ill-conditioned that oracle and device, two independent solvers, end in different
         # places far from any valley: 1 marker in 1300 of an unrestricted sweep; every discrete output still agreed)
         h = int(rng.integers(max(160, w // 2), min(1100, 2 * w) + 1))
+    if os.environ.get("FUZZ_RANDOM_SIZES") == "2":   # small frames: crops and frames a few strips or less wide, markers cut by the edge
+        w = int(rng.integers(64, 320))
+        h = int(rng.integers(max(64, w // 2), min(320, 2 * w) + 1))
     names = [H.TEMPLATE_ORDER[i] for i in sorted(rng.choice(3, size=int(rng.integers(1, 4)), replace=False))]
     if s % 2:   # every other scene: code grids up to 8x8 (opencvar.h:174-175) -- the pinned synthetic ones and freshly drawn grids
         pool = list(H.BIG_TEMPLATES)
