@@ -30,6 +30,8 @@ for s in range(n_scenes):
         # lengths 6:1 -- the planar pose fit is so ill-conditioned that oracle and device, two independent solvers, end in different
         # places far from any valley: 1 marker in 1300 of an unrestricted sweep; every discrete output still agreed)
         h = int(rng.integers(max(160, w // 2), min(1100, 2 * w) + 1))
+    if os.environ.get("FUZZ_RANDOM_SIZES") == "3":   # large frames (the marker grid below grows with them: up to 6 x 4 markers)
+        w, h = [(3840, 2160), (2560, 1440), (2048, 1536), (3001, 1701)][int(rng.integers(4))]
     if os.environ.get("FUZZ_RANDOM_SIZES") == "2":   # small frames: crops and frames a few strips or less wide, markers cut by the edge
         w = int(rng.integers(64, 320))
         h = int(rng.integers(max(64, w // 2), min(320, 2 * w) + 1))
